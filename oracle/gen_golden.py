@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  TEST INFRASTRUCTURE — runs ONLY in the build container.
+
+Imports the reference implementation from /root/reference (read-only, CPU, torch 2.10) and records
+seeded inputs -> reference outputs as small fixtures under tests/golden/.  The reference never
+travels to the GPU box; only these .npz data files (inputs + expected outputs) do.
+
+What is pinned:
+  por_*   : POR.por_residual_update        (/root/reference/agent/por.py:73-112)
+  sorl_*  : SORL.update / SORL.vf_update   (/root/reference/agent/sorl.py:78-152), backbone=None
+  cql_*   : CQLTrainer.learn               (/root/reference/src/porl/train/cql_trainer.py:88-124)
+            called as unbound methods on object.__new__(CQLTrainer) — the constructor is broken
+            upstream; gymnasium/ipdb/tensorboard are stubbed (not installed).
+  replay_*: ReplayBuffer.push/sample index streams under np.random.seed
+            (/root/reference/buffer/replay_buffer.py:33-75)
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py </dev/null
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "src"))
+sys.dont_write_bytecode = True
+
+from porl_amd.util.synth import make_rows, split_rows, make_discrete_transitions  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def sd_np(module_or_sd):
+    sd = module_or_sd.state_dict() if hasattr(module_or_sd, "state_dict") else module_or_sd
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+def adam_np(opt, names):
+    """Flatten torch Adam state to {name.exp_avg, name.exp_avg_sq} + step; `names` orders params."""
+    out = {}
+    params = [p for g in opt.param_groups for p in g["params"]]
+    assert len(params) == len(names)
+    step = None
+    for n, p in zip(names, params):
+        st = opt.state[p]
+        out[n + ".exp_avg"] = st["exp_avg"].numpy().copy()
+        out[n + ".exp_avg_sq"] = st["exp_avg_sq"].numpy().copy()
+        step = float(st["step"])
+    out["__step__"] = np.float64(step)
+    return out
+
+
+def checksum(arr: np.ndarray, salt: int):
+    """(sum, abs-sum, 16 sampled values) in float64 — compact pin for tensors too big to store."""
+    a = arr.astype(np.float64).ravel()
+    idx = np.random.default_rng(1000 + salt).integers(0, a.size, size=16)
+    return np.concatenate([[a.sum(), np.abs(a).sum()], a[idx]])
+
+
+def pack(prefix, d):
+    return {prefix + k: v for k, v in d.items()}
+
+
+# --------------------------------------------------------------------------------------------
+def gen_por(name, S, H, L, layer_norm, B, K, full, seed_model=0, seed_data=1, A=2,
+            tau=0.9, alpha=10.0, max_steps=1000):
+    from agent.por import POR
+    args = SimpleNamespace(state_size=S, hidden_dim=H, n_hidden=L, layer_norm=layer_norm,
+                           feature_dim=256, action_size=A)
+    torch.manual_seed(seed_model)
+    agent = POR(args, max_steps, tau, alpha)
+    rows = make_rows(K * B, S, A, seed=seed_data)
+    init = sd_np(agent)
+    v_losses, g_losses, lrs = [], [], []
+    for k in range(K):
+        batch = torch.from_numpy(rows[k * B:(k + 1) * B])
+        s, r, sp, d, a = split_rows(batch, S, A)
+        vl, gl = agent.por_residual_update(s, sp, r, d)
+        v_losses.append(vl)
+        g_losses.append(gl)
+        lrs.append(agent.goal_lr_schedule.get_last_lr()[0])
+    final = sd_np(agent)
+    meta = dict(S=S, H=H, L=L, layer_norm=int(layer_norm), B=B, K=K, A=A, seed_model=seed_model,
+                seed_data=seed_data, tau=tau, alpha=alpha, max_steps=max_steps,
+                discount=0.99, beta=0.005, value_lr=1e-4, policy_lr=1e-4)
+    out = {"meta_" + k: np.float64(v) for k, v in meta.items()}
+    out["v_loss"] = np.array(v_losses, dtype=np.float64)
+    out["g_loss"] = np.array(g_losses, dtype=np.float64)
+    out["goal_lr_after"] = np.array(lrs, dtype=np.float64)
+    keys = list(final.keys())
+    out["keys"] = np.array(keys)
+    vf_names = [n for n, _ in agent.vf.named_parameters(prefix="vf")]
+    gp_names = [n for n, _ in agent.goal_policy.named_parameters(prefix="goal_policy")]
+    if full:
+        out.update(pack("init/", init))
+        out.update(pack("final/", final))
+        out.update(pack("adam_v/", adam_np(agent.v_optimizer, vf_names)))
+        out.update(pack("adam_g/", adam_np(agent.goal_policy_optimizer, gp_names)))
+    else:
+        out["init_cks"] = np.stack([checksum(init[k], i) for i, k in enumerate(keys)])
+        out["final_cks"] = np.stack([checksum(final[k], i) for i, k in enumerate(keys)])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: v_loss={v_losses} g_loss={g_losses}")
+
+
+def gen_sorl(name, S, H, L, layer_norm, B, K, A=2, alpha=3.0, tau=0.9, seed_model=0, seed_data=2,
+             max_steps=1000, vf_only=False):
+    from agent.sorl import SORL
+    args = SimpleNamespace(state_size=S, hidden_dim=H, n_hidden=L, layer_norm=layer_norm,
+                           feature_dim=256, action_size=A)
+    torch.manual_seed(seed_model)
+    agent = SORL(args, max_steps, tau, alpha)
+    rows = make_rows(K * B, S, A, seed=seed_data)
+    init = sd_np(agent)
+    v_losses, g_losses = [], []
+    for k in range(K):
+        batch = torch.from_numpy(rows[k * B:(k + 1) * B])
+        s, r, sp, d, a = split_rows(batch, S, A)
+        if vf_only:
+            v_losses.append(agent.vf_update(s, a, r, sp, d))
+        else:
+            vl, gl = agent.update(s, a, r, sp, d)
+            v_losses.append(vl)
+            g_losses.append(gl)
+    final = sd_np(agent)
+    # select_action on the first 8 observations with the final weights (sorl.py:71-76)
+    act = agent.select_action(torch.from_numpy(rows[:8, :S].copy()))
+    meta = dict(S=S, H=H, L=L, layer_norm=int(layer_norm), B=B, K=K, A=A, seed_model=seed_model,
+                seed_data=seed_data, tau=tau, alpha=alpha, max_steps=max_steps,
+                discount=0.99, beta=0.005, value_lr=1e-4, policy_lr=1e-4, vf_only=int(vf_only))
+    out = {"meta_" + k: np.float64(v) for k, v in meta.items()}
+    out["v_loss"] = np.array(v_losses, dtype=np.float64)
+    out["g_loss"] = np.array(g_losses, dtype=np.float64)
+    out["select_action"] = act
+    out["keys"] = np.array(list(final.keys()))
+    out.update(pack("init/", init))
+    out.update(pack("final/", final))
+    v_names = [n for n, _ in agent.v_net.named_parameters(prefix="v_net")]
+    p_names = [n for n, _ in agent.policy.named_parameters(prefix="policy")]
+    out.update(pack("adam_v/", adam_np(agent.v_optimizer, v_names)))
+    if not vf_only:
+        out.update(pack("adam_g/", adam_np(agent.policy_optimizer, p_names)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: v_loss={v_losses} g_loss={g_losses}")
+
+
+def _stub_cql_imports():
+    """gymnasium / ipdb / tensorboard are not installed; porl.train imports them at module scope."""
+    for mod in ("gymnasium", "ipdb", "tensorboard", "torch.utils.tensorboard", "matplotlib",
+                "matplotlib.pyplot"):
+        if mod not in sys.modules:
+            try:
+                __import__(mod)
+            except Exception:
+                m = types.ModuleType(mod)
+                m.__path__ = []
+                sys.modules[mod] = m
+    tb = sys.modules["torch.utils.tensorboard"]
+    if not hasattr(tb, "SummaryWriter"):
+        class SummaryWriter:  # no-op
+            def __init__(self, *a, **k): pass
+            def add_scalar(self, *a, **k): pass
+            def add_hparams(self, *a, **k): pass
+            def close(self): pass
+        tb.SummaryWriter = SummaryWriter
+    sys.modules["ipdb"].set_trace = lambda *a, **k: None
+    gym = sys.modules["gymnasium"]
+    if not hasattr(gym, "Env"):
+        gym.Env = object
+        gym.make = lambda *a, **k: None
+        gym.spaces = types.ModuleType("gymnasium.spaces")
+
+
+def gen_cql(name, S, A, B, K, N, seed_model=0, seed_data=3, seed_np=7, sync_every=2, gamma=0.99,
+            alpha=1):
+    _stub_cql_imports()
+    from porl.train.cql_trainer import CQLTrainer
+    from porl.net.q_network import QNetwork
+    from porl.buffer.replaybuffer import ReplayBuffer
+    dev = torch.device("cpu")
+    torch.manual_seed(seed_model)
+    t = object.__new__(CQLTrainer)
+    # mirrors dqn_trainer.py:66-71 (nets, load_state_dict, Adam lr=5e-4)
+    t.q_network = QNetwork(S, A).to(dev)
+    t.target_network = QNetwork(S, A).to(dev)
+    t.target_network.load_state_dict(t.q_network.state_dict())
+    t.target_network.eval()
+    t.optimizer = torch.optim.Adam(t.q_network.parameters(), lr=0.0005)
+    t.replay_buffer = ReplayBuffer(N, (S,), dev)
+    t.batch_size, t.gamma, t.alpha, t.action_size, t.device = B, gamma, alpha, A, dev
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=seed_data)
+    for i in range(N):
+        t.replay_buffer.push(st[i], int(ac[i]), float(rw[i]), ns[i], bool(dn[i]))
+    init = sd_np(t.q_network)
+    np.random.seed(seed_np)
+    # record the index stream the reference's sampler will draw, then replay the same seed
+    idx = np.stack([np.random.choice(N, B, replace=False) for _ in range(K)])
+    np.random.seed(seed_np)
+    losses = []
+    for k in range(K):
+        losses.append(CQLTrainer.learn(t))
+        if (k + 1) % sync_every == 0:  # hard target sync, dqn_trainer.py:195-196
+            t.target_network.load_state_dict(t.q_network.state_dict())
+    # one standalone penalty evaluation (cql_trainer.py:60-86) on the first K-step batch
+    pen = float(CQLTrainer.compute_cql_penalty(t, torch.from_numpy(st[idx[0]]),
+                                               torch.from_numpy(ac[idx[0]])))
+    final = sd_np(t.q_network)
+    final_t = sd_np(t.target_network)
+    names = [n for n, _ in t.q_network.named_parameters()]
+    meta = dict(S=S, A=A, B=B, K=K, N=N, seed_model=seed_model, seed_data=seed_data, seed_np=seed_np,
+                sync_every=sync_every, gamma=gamma, alpha=alpha, lr=0.0005)
+    out = {"meta_" + k: np.float64(v) for k, v in meta.items()}
+    out["loss"] = np.array(losses, dtype=np.float64)
+    out["indices"] = idx
+    out["penalty_final_on_batch0"] = np.float64(pen)
+    out["keys"] = np.array(list(final.keys()))
+    out.update(pack("init/", init))
+    out.update(pack("final/", final))
+    out.update(pack("final_target/", final_t))
+    out.update(pack("adam/", adam_np(t.optimizer, names)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={losses} pen={pen}")
+
+
+def gen_replay(name, N, cap, S, B, K, seed_np=11):
+    from buffer.replay_buffer import ReplayBuffer
+    rb = ReplayBuffer(cap, (S,), torch.device("cpu"))
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, 4, seed=5)
+    for i in range(N):  # N > cap exercises the ring wrap (replay_buffer.py:50-51)
+        rb.push(st[i], int(ac[i]), float(rw[i]), ns[i], bool(dn[i]))
+    np.random.seed(seed_np)
+    samples = [rb.sample(B) for _ in range(K)]
+    out = dict(meta_N=np.float64(N), meta_cap=np.float64(cap), meta_S=np.float64(S),
+               meta_B=np.float64(B), meta_K=np.float64(K), meta_seed_np=np.float64(seed_np),
+               size=np.float64(len(rb)), position=np.float64(rb.position))
+    for k, (s, a, r, n, d) in enumerate(samples):
+        out[f"s{k}"] = s.numpy(); out[f"a{k}"] = a.numpy(); out[f"r{k}"] = r.numpy()
+        out[f"n{k}"] = n.numpy(); out[f"d{k}"] = d.numpy()
+    out["dtype_names"] = np.array([str(t.dtype) for t in samples[0]])
+    # B > size must raise ValueError (numpy), replay_buffer.py:64
+    try:
+        rb.sample(len(rb) + 1)
+        out["oversample_raises"] = np.float64(0)
+    except ValueError:
+        out["oversample_raises"] = np.float64(1)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: size={len(rb)} pos={rb.position}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    # POR — small, fully stored
+    gen_por("por_s60_h64_b32", S=60, H=64, L=2, layer_norm=False, B=32, K=5, full=True)
+    gen_por("por_s60_h64_b32_ln", S=60, H=64, L=2, layer_norm=True, B=32, K=5, full=True)
+    gen_por("por_s17_h48_l3_b50", S=17, H=48, L=3, layer_norm=False, B=50, K=4, full=True,
+            seed_model=3, seed_data=4)                       # ragged dims, 3 hidden layers
+    gen_por("por_s60_h256_b256", S=60, H=256, L=2, layer_norm=False, B=256, K=3, full=False)
+    # BASELINE configs 1/2 — checksums only (5.6 M params)
+    gen_por("por_s60_h1024_b256", S=60, H=1024, L=2, layer_norm=False, B=256, K=3, full=False)
+    gen_por("por_s60_h1024_b1024", S=60, H=1024, L=2, layer_norm=False, B=1024, K=3, full=False)
+    gen_por("por_s60_h1024_b1024_ln", S=60, H=1024, L=2, layer_norm=True, B=1024, K=2, full=False)
+    # SORL (backbone=None): alpha MULTIPLIES (sorl.py:104)
+    gen_sorl("sorl_s60_h64_b32", S=60, H=64, L=2, layer_norm=False, B=32, K=5, alpha=3.0)
+    gen_sorl("sorl_s362_h64_b16_a10", S=362, H=64, L=2, layer_norm=False, B=16, K=3, alpha=10.0)
+    gen_sorl("sorl_vf_s60_h64_b32", S=60, H=64, L=2, layer_norm=False, B=32, K=3, vf_only=True)
+    # CQL
+    gen_cql("cql_s60_a10_b64", S=60, A=10, B=64, K=6, N=2000)
+    gen_cql("cql_s8_a4_b256", S=8, A=4, B=256, K=4, N=1000, seed_model=1, seed_np=9)
+    # Replay buffer
+    gen_replay("replay_ring", N=700, cap=512, S=8, B=64, K=3)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+"""Pins oracle/por_oracle.py against golden vectors recorded from the reference itself
+(oracle/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, sub, checksum
+from oracle.por_oracle import PorOracle, sorl_oracle, CqlOracle
+from porl_amd.util.synth import make_rows, split_rows, make_discrete_transitions
+
+LOSS_RTOL = 1e-5
+PARAM_ATOL = 1e-5
+
+
+def _assert_params(P, final, atol=PARAM_ATOL):
+    for k, ref in final.items():
+        got = P[k]
+        assert got.shape == ref.shape, k
+        err = np.abs(got.astype(np.float64) - ref).max() if ref.size else 0.0
+        assert err <= atol, f"{k}: max-abs {err:.3e}"
+
+
+def _run_por(z, meta, init):
+    S, H, L, B, K, A = (int(meta[k]) for k in ("S", "H", "L", "B", "K", "A"))
+    o = PorOracle(init, S, H, L, bool(meta["layer_norm"]), tau=meta["tau"], alpha=meta["alpha"],
+                  max_steps=int(meta["max_steps"]))
+    rows = make_rows(K * B, S, A, seed=int(meta["seed_data"]))
+    vl, gl = [], []
+    for k in range(K):
+        s, r, sp, d, a = split_rows(rows[k * B:(k + 1) * B], S, A)
+        v, g = o.por_residual_update(s, sp, r, d)
+        vl.append(v)
+        gl.append(g)
+    np.testing.assert_allclose(vl, z["v_loss"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(gl, z["g_loss"], rtol=LOSS_RTOL)
+    return o
+
+
+@pytest.mark.parametrize("name", ["por_s60_h64_b32", "por_s60_h64_b32_ln", "por_s17_h48_l3_b50"])
+def test_por_small_full(name):
+    z, meta = load_golden(name)
+    o = _run_por(z, meta, sub(z, "init/"))
+    _assert_params(o.P, sub(z, "final/"))
+    am = sub(z, "adam_v/")
+    assert o.adam_v.step == int(am["__step__"])
+    for n in o.vf_names:
+        np.testing.assert_allclose(o.adam_v.m[n], am[n + ".exp_avg"], atol=1e-7, rtol=1e-4)
+        np.testing.assert_allclose(o.adam_v.v[n], am[n + ".exp_avg_sq"], atol=1e-9, rtol=1e-4)
+    ag = sub(z, "adam_g/")
+    for n in o.pol_names:
+        np.testing.assert_allclose(o.adam_g.m[n], ag[n + ".exp_avg"], atol=1e-6, rtol=1e-4)
+    # cosine schedule value after each update (por.py:110)
+    from oracle.por_oracle import cosine_lr
+    want = [cosine_lr(meta["policy_lr"], t + 1, int(meta["max_steps"])) for t in range(int(meta["K"]))]
+    np.testing.assert_allclose(want, z["goal_lr_after"], rtol=1e-12)
+
+
+def _seeded_init(meta, sorl=False):
+    """Large cases store only checksums; the initial weights are rebuilt with torch's seeded
+    default init in the reference's construction order and checked."""
+    torch = pytest.importorskip("torch")
+    from porl_amd.util.init import build_por_state_dict
+    return build_por_state_dict(int(meta["S"]), int(meta["H"]), int(meta["L"]), bool(meta["layer_norm"]),
+                                seed=int(meta["seed_model"]))
+
+
+@pytest.mark.parametrize("name", ["por_s60_h256_b256", "por_s60_h1024_b256", "por_s60_h1024_b1024",
+                                  "por_s60_h1024_b1024_ln"])
+def test_por_large_checksums(name):
+    z, meta = load_golden(name)
+    init = _seeded_init(meta)
+    keys = [str(k) for k in z["keys"]]
+    assert list(init.keys()) == keys
+    for i, k in enumerate(keys):
+        np.testing.assert_allclose(checksum(init[k], i), z["init_cks"][i], rtol=0, atol=0)
+    o = _run_por(z, meta, init)
+    for i, k in enumerate(keys):
+        got, ref = checksum(o.P[k], i), z["final_cks"][i]
+        n = o.P[k].size
+        # sampled elements: plain tolerance; sums: tolerance scaled by element count
+        np.testing.assert_allclose(got[2:], ref[2:], atol=PARAM_ATOL, rtol=0, err_msg=k)
+        assert abs(got[0] - ref[0]) <= PARAM_ATOL * max(1.0, np.sqrt(n)), k
+        assert abs(got[1] - ref[1]) <= PARAM_ATOL * max(1.0, np.sqrt(n)) * 4, k
+
+
+@pytest.mark.parametrize("name", ["sorl_s60_h64_b32", "sorl_s362_h64_b16_a10"])
+def test_sorl_update(name):
+    z, meta = load_golden(name)
+    S, H, L, B, K, A = (int(meta[k]) for k in ("S", "H", "L", "B", "K", "A"))
+    o = sorl_oracle(sub(z, "init/"), S, H, L, bool(meta["layer_norm"]), tau=meta["tau"],
+                    alpha=meta["alpha"], max_steps=int(meta["max_steps"]))
+    rows = make_rows(K * B, S, A, seed=int(meta["seed_data"]))
+    for k in range(K):
+        s, r, sp, d, a = split_rows(rows[k * B:(k + 1) * B], S, A)
+        v, g = o.sorl_update(s, a, r, sp, d)
+        np.testing.assert_allclose(v, z["v_loss"][k], rtol=LOSS_RTOL)
+        np.testing.assert_allclose(g, z["g_loss"][k], rtol=2e-5)
+    _assert_params(o.P, sub(z, "final/"))
+    np.testing.assert_allclose(o.select_action(rows[:8, :S]), z["select_action"], atol=1e-6)
+
+
+def test_sorl_vf_update():
+    z, meta = load_golden("sorl_vf_s60_h64_b32")
+    S, H, L, B, K, A = (int(meta[k]) for k in ("S", "H", "L", "B", "K", "A"))
+    o = sorl_oracle(sub(z, "init/"), S, H, L, False, tau=meta["tau"], alpha=meta["alpha"])
+    rows = make_rows(K * B, S, A, seed=int(meta["seed_data"]))
+    for k in range(K):
+        s, r, sp, d, a = split_rows(rows[k * B:(k + 1) * B], S, A)
+        np.testing.assert_allclose(o.sorl_vf_update(s, a, r, sp, d), z["v_loss"][k], rtol=LOSS_RTOL)
+    _assert_params(o.P, sub(z, "final/"))
+
+
+@pytest.mark.parametrize("name", ["cql_s60_a10_b64", "cql_s8_a4_b256"])
+def test_cql_learn(name):
+    z, meta = load_golden(name)
+    S, A, B, K, N = (int(meta[k]) for k in ("S", "A", "B", "K", "N"))
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=int(meta["seed_data"]))
+    o = CqlOracle(sub(z, "init/"), A, gamma=meta["gamma"], alpha=meta["alpha"], lr=meta["lr"])
+    for k in range(K):
+        idx = z["indices"][k]
+        loss = o.learn(st[idx], ac[idx], rw[idx], ns[idx], dn[idx])
+        np.testing.assert_allclose(loss, z["loss"][k], rtol=LOSS_RTOL)
+        if (k + 1) % int(meta["sync_every"]) == 0:
+            o.sync_target()
+    _assert_params(o.Q, sub(z, "final/"))
+    _assert_params(o.T, sub(z, "final_target/"))
+    idx = z["indices"][0]
+    np.testing.assert_allclose(o.penalty(st[idx], ac[idx]), float(z["penalty_final_on_batch0"]),
+                               atol=2e-6)
