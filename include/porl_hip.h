@@ -1,0 +1,176 @@
+/*
+ * porl_hip.h — C ABI of libporl_hip.so: the MI355X (gfx950) engine for porl's batched offline-RL
+ * update step.  Plain pointers and sizes only; no torch types.  All device pointers are fp32 unless
+ * noted; every call enqueues on `stream` (a hipStream_t passed as void*) and returns without
+ * synchronising.  Return value: 0 on success, a negative PORL_ERR_* or a positive hipError_t.
+ *
+ * The reference (/root/reference, Python) has no FFI layer; each entry point below names the
+ * reference Python interface it replaces, and INTEGRATION.md shows the ctypes stub a maintainer
+ * would add on the reference side.
+ */
+#ifndef PORL_HIP_H
+#define PORL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PORL_ABI_VERSION 1
+#define PORL_MAX_HIDDEN 8
+
+#define PORL_OK 0
+#define PORL_ERR_INVALID (-1)      /* bad argument / shape */
+#define PORL_ERR_UNSUPPORTED (-2)  /* configuration not implemented on device yet */
+#define PORL_ERR_UNBOUND (-3)      /* engine used before porl_iql_bind() */
+
+int porl_abi_version(void);
+/* Human-readable text for the last failing call on this thread. */
+const char* porl_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * IQL-family engine: POR (agent/por.py:20-112) and SORL (agent/sorl.py:20-152) share one value
+ * step (twin-V expectile regression against an EMA target) and an advantage-weighted Gaussian
+ * regression step; they differ in the regression target, the mean's output activation and the
+ * weight formula.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct porl_iql_cfg {
+  int32_t obs_dim;      /* S: input width of vf / policy (args.state_size or args.feature_dim)       */
+  int32_t pol_out_dim;  /* POR: S (goal policy predicts s', por.py:36-39); SORL: args.action_size     */
+  int32_t hidden_dim;   /* args.hidden_dim                                                            */
+  int32_t n_hidden;     /* args.n_hidden (>= 1)                                                       */
+  int32_t layer_norm;   /* args.layer_norm: LayerNorm in TwinV only (value_functions.py:35-36)        */
+  int32_t pol_tanh;     /* 1 = BoundedGaussianPolicy (policy.py:35-59), 0 = GaussianPolicy (:12-33)   */
+  int32_t weight_mode;  /* 0 = exp(adv/alpha) (por.py:100), 1 = exp(alpha*adv) (sorl.py:104)          */
+  int32_t max_batch;    /* workspace is sized for this many rows per call                             */
+} porl_iql_cfg;
+
+typedef struct porl_iql porl_iql;   /* opaque host-side handle; owns no device memory */
+
+int porl_iql_create(const porl_iql_cfg* cfg, porl_iql** out);
+void porl_iql_destroy(porl_iql* h);
+
+/* Parameter groups.  Each group is ONE flat fp32 range so Adam/EMA/all-reduce are single sweeps;
+ * tensors start on 16-byte boundaries, padding floats stay zero.
+ *   group 0 "vf"     : TwinV  v1 then v2; per net, per Linear: weight (out,in), bias (out)
+ *                       [, LayerNorm weight, bias after each hidden Linear when layer_norm]
+ *   group 1 "policy" : log_std (pol_out_dim) first, then net Linear weights/biases
+ * The EMA target network uses the layout of group 0.  Tensor order inside a group equals
+ * nn.Module.named_parameters() order of the reference modules. */
+int64_t porl_iql_group_floats(const porl_iql* h, int group);
+int32_t porl_iql_group_tensors(const porl_iql* h, int group);
+/* rows == 0 marks a 1-D tensor of `cols` elements. */
+int porl_iql_tensor_info(const porl_iql* h, int group, int index, int64_t* offset, int32_t* rows,
+                         int32_t* cols);
+
+int64_t porl_iql_workspace_floats(const porl_iql* h);
+
+typedef struct porl_iql_buffers {
+  float* params_vf;   /* group 0 floats */
+  float* params_tgt;  /* group 0 floats (v_target / v_tgt) */
+  float* params_pol;  /* group 1 floats */
+  float* grads_vf;
+  float* grads_pol;
+  float* adam_m_vf;   /* exp_avg    */
+  float* adam_v_vf;   /* exp_avg_sq */
+  float* adam_m_pol;
+  float* adam_v_pol;
+  float* workspace;   /* porl_iql_workspace_floats() floats, 16-byte aligned */
+  float* stats;       /* >= 8 floats: [0] v_loss, [1] g_loss, [2] min NLL of the batch (por.py:104) */
+} porl_iql_buffers;
+
+int porl_iql_bind(porl_iql* h, const porl_iql_buffers* bufs);
+
+/* Minibatch hand-over (replaces the tensor arguments of POR.por_residual_update, por.py:73, and
+ * SORL.update, sorl.py:78).  Inputs may be strided column slices of one packed (B,row) tensor
+ * (por_train.py:74-78): *_rs are row strides in floats, matrices have unit column stride, vectors
+ * have element stride *_rs.  `pol_target` is s' for POR and the action matrix for SORL; it may be NULL
+ * when only the value step is run.  Caller keeps ownership; inputs are not modified. */
+int porl_iql_load_batch(porl_iql* h, int32_t batch,
+                        const float* obs, int64_t obs_rs,
+                        const float* next_obs, int64_t next_rs,
+                        const float* rew, int64_t rew_rs,
+                        const float* term, int64_t term_rs,
+                        const float* pol_target, int64_t pt_rs,
+                        void* stream);
+
+typedef struct porl_iql_hyper {
+  float tau;         /* expectile                                   */
+  float discount;    /* gamma                                       */
+  float alpha;       /* advantage temperature                       */
+  float ema_beta;    /* Polyak coefficient (por.py:31, beta=0.005)  */
+  float inv_batch;   /* 1/B_global: a data-parallel shard passes 1/(world*B_local) */
+  float value_lr;    /* constant (no schedule on the value optimizer) */
+  float policy_lr;   /* CosineAnnealingLR value for THIS update (host-computed, Appendix A.3) */
+  int32_t value_step;   /* Adam step counter t >= 1 of the value optimizer for this update  */
+  int32_t policy_step;  /* ditto for the policy optimizer                                   */
+  float adam_beta1, adam_beta2, adam_eps;   /* torch defaults 0.9, 0.999, 1e-8 */
+} porl_iql_hyper;
+
+/* por.py:81-89 — target-V forward, TD target, twin forward, expectile loss, backward.
+ * Leaves dL/dtheta in grads_vf and stats[0] = this rank's share of v_loss.  (A data-parallel
+ * caller all-reduces grads_vf and stats[0] here.) */
+int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream);
+/* por.py:90-93 — Adam on vf, then v_target <- (1-beta) v_target + beta vf, one fused sweep. */
+int porl_iql_value_apply(porl_iql* h, const porl_iql_hyper* hp, void* stream);
+/* por.py:97-108 — second twin forward with the updated vf, advantage weights, policy forward,
+ * weighted NLL, backward.  Leaves grads_pol, stats[1] = g_loss share, stats[2] = min NLL. */
+int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream);
+/* por.py:109 — Adam on the policy (lr = hp->policy_lr). */
+int porl_iql_policy_apply(porl_iql* h, const porl_iql_hyper* hp, void* stream);
+/* The four phases back to back (single-GPU update; batch must have been loaded). */
+int porl_iql_step(porl_iql* h, const porl_iql_hyper* hp, void* stream);
+
+/* Forward-only paths: TwinV.both (value_functions.py:38-39) on vf (which=0) or the target (which=1),
+ * and the policy mean (policy.py:19 / sorl.py:71-76).  x is (batch, obs_dim) with row stride x_rs. */
+int porl_iql_forward_value(porl_iql* h, int which, const float* x, int64_t x_rs, int32_t batch,
+                           float* v1_out, float* v2_out, void* stream);
+int porl_iql_forward_policy(porl_iql* h, const float* x, int64_t x_rs, int32_t batch, float* mean_out,
+                            int64_t mean_rs, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Building blocks, exported for tests, the replay buffer and other trainers
+ * --------------------------------------------------------------------------------------------- */
+/* C = epilogue(op(A) * op(B)); mode 0 "NT": A (M,K), B (N,K); 1 "NN": A (M,K), B (K,N);
+ * 2 "TN": A (K,M), B (K,N).  act: 0 none, 1 relu, 2 tanh.  bias (N) / mask (M,N; ld=ldmask) may be
+ * NULL.  tile: 0 128x128, 1 128x64, 2 64x128, 3 64x64, -1 auto.  splitk > 1 needs `slab`
+ * (splitk*M*ldc floats) and is combined in fixed order. */
+int porl_gemm_f32(int mode, int tile, int32_t M, int32_t N, int32_t K,
+                  const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc,
+                  const float* bias, int act, const float* mask, int32_t ldmask,
+                  int splitk, float* slab, void* stream);
+
+/* torch.optim.Adam single-tensor arithmetic over a flat range (n multiple of 4, 16-byte aligned),
+ * optionally fused with target <- (1-ema_beta) target + ema_beta p (target may be NULL). */
+int porl_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t n,
+                  float lr, int32_t step, float beta1, float beta2, float eps, float ema_beta,
+                  void* stream);
+
+/* out[i,:] = rows[idx[i],:] — minibatch gather from a device-resident packed-row replay store
+ * (replaces the numpy fancy-index + H2D copies of ReplayBuffer.sample, buffer/replay_buffer.py:64-73). */
+int porl_gather_rows(const float* rows, int64_t row_stride, const int64_t* idx, int32_t n,
+                     int32_t width, float* out, int64_t out_stride, void* stream);
+
+/* `batch` distinct indices base + perm_{seed,step}(i), i < batch, perm a keyed bijection of [0, n_rows):
+ * uniform sampling WITHOUT replacement on the device (semantics of np.random.choice(size, B,
+ * replace=False), buffer/replay_buffer.py:64; the stream differs from numpy's). */
+int porl_sample_indices(int64_t n_rows, int32_t batch, uint64_t seed, uint64_t step, int64_t base,
+                        int64_t* out, void* stream);
+
+/* Per-launch timing with HIP events on the launch stream (off by default; adds two event records per
+ * kernel).  porl_prof_read synchronises the device and returns the number of entries filled. */
+typedef struct porl_prof_entry {
+  char name[96];
+  int64_t launches;
+  double total_ms;
+  double flops;   /* algorithmic, summed over launches (GEMMs: 2*M*N*K per problem) */
+  double bytes;   /* algorithmic operand + result bytes, summed over launches */
+} porl_prof_entry;
+int porl_prof_enable(int on);
+int porl_prof_read(porl_prof_entry* out, int max_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PORL_HIP_H */

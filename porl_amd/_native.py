@@ -1,0 +1,125 @@
+"""ctypes binding of libporl_hip.so (C ABI in include/porl_hip.h).
+
+There is NO CPU fallback: if the library is missing or does not load, importing a compute entry
+point raises.  Build it with `python -m porl_amd.build` (or `__graft_entry__.build()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libporl_hip.so")
+
+ABI_VERSION = 1
+
+# every symbol include/porl_hip.h declares (tests check the .so exports exactly these)
+SYMBOLS = [
+    "porl_abi_version", "porl_last_error",
+    "porl_iql_create", "porl_iql_destroy", "porl_iql_group_floats", "porl_iql_group_tensors",
+    "porl_iql_tensor_info", "porl_iql_workspace_floats", "porl_iql_bind", "porl_iql_load_batch",
+    "porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_backward",
+    "porl_iql_policy_apply", "porl_iql_step", "porl_iql_forward_value", "porl_iql_forward_policy",
+    "porl_gemm_f32", "porl_adam_ema", "porl_gather_rows", "porl_sample_indices",
+    "porl_prof_enable", "porl_prof_read",
+]
+
+
+class IqlCfg(C.Structure):
+    _fields_ = [("obs_dim", C.c_int32), ("pol_out_dim", C.c_int32), ("hidden_dim", C.c_int32),
+                ("n_hidden", C.c_int32), ("layer_norm", C.c_int32), ("pol_tanh", C.c_int32),
+                ("weight_mode", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class IqlBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("params_vf", "params_tgt", "params_pol", "grads_vf", "grads_pol", "adam_m_vf",
+                 "adam_v_vf", "adam_m_pol", "adam_v_pol", "workspace", "stats")]
+
+
+class IqlHyper(C.Structure):
+    _fields_ = [("tau", C.c_float), ("discount", C.c_float), ("alpha", C.c_float),
+                ("ema_beta", C.c_float), ("inv_batch", C.c_float), ("value_lr", C.c_float),
+                ("policy_lr", C.c_float), ("value_step", C.c_int32), ("policy_step", C.c_int32),
+                ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float)]
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _declare(lib):
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.porl_abi_version.restype = C.c_int
+    lib.porl_last_error.restype = C.c_char_p
+    lib.porl_iql_create.argtypes = [C.POINTER(IqlCfg), C.POINTER(vp)]
+    lib.porl_iql_destroy.argtypes = [vp]
+    lib.porl_iql_destroy.restype = None
+    lib.porl_iql_group_floats.argtypes = [vp, C.c_int]
+    lib.porl_iql_group_floats.restype = i64
+    lib.porl_iql_group_tensors.argtypes = [vp, C.c_int]
+    lib.porl_iql_group_tensors.restype = i32
+    lib.porl_iql_tensor_info.argtypes = [vp, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
+    lib.porl_iql_workspace_floats.argtypes = [vp]
+    lib.porl_iql_workspace_floats.restype = i64
+    lib.porl_iql_bind.argtypes = [vp, C.POINTER(IqlBuffers)]
+    lib.porl_iql_load_batch.argtypes = [vp, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp]
+    for name in ("porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_backward",
+                 "porl_iql_policy_apply", "porl_iql_step"):
+        getattr(lib, name).argtypes = [vp, C.POINTER(IqlHyper), vp]
+    lib.porl_iql_forward_value.argtypes = [vp, C.c_int, vp, i64, i32, vp, vp, vp]
+    lib.porl_iql_forward_policy.argtypes = [vp, vp, i64, i32, vp, i64, vp]
+    lib.porl_gemm_f32.argtypes = [C.c_int, C.c_int, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, C.c_int,
+                                  vp, i32, C.c_int, vp, vp]
+    lib.porl_adam_ema.argtypes = [vp, vp, vp, vp, vp, i64, f32, i32, f32, f32, f32, f32, vp]
+    lib.porl_gather_rows.argtypes = [vp, i64, vp, i32, i32, vp, i64, vp]
+    lib.porl_sample_indices.argtypes = [i64, i32, C.c_uint64, C.c_uint64, i64, vp, vp]
+    lib.porl_prof_enable.argtypes = [C.c_int]
+    lib.porl_prof_read.argtypes = [C.POINTER(ProfEntry), C.c_int]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("porl_abi_version",):
+            fn.restype = C.c_int
+
+
+def lib():
+    """Load (once) and return the shared library; raises NativeError when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(f"{LIB_PATH} not found — run `python -m porl_amd.build` "
+                              "(hipcc --offload-arch=gfx950); porl_amd has no CPU fallback")
+        try:
+            l = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise NativeError(f"cannot load {LIB_PATH}: {e}") from e
+        _declare(l)
+        v = l.porl_abi_version()
+        if v != ABI_VERSION:
+            raise NativeError(f"libporl_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().porl_last_error().decode("utf-8", "replace")
+        raise NativeError(f"{what or 'porl_hip'} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

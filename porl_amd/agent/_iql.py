@@ -1,0 +1,204 @@
+"""Shared host logic of the POR and SORL agents: parameter adoption into the engine's flat groups,
+optimizer / scheduler facades with torch-compatible state, and the (optionally data-parallel) update.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+
+from ..engine import IqlEngine
+from ..parallel import GradExchange
+
+
+class ArenaAdam:
+    """torch.optim.Adam look-alike over one flat parameter group of the engine.
+
+    Arithmetic follows torch's single-tensor Adam; the sweep itself is the HIP
+    kernel `adam_ema_kernel`.  `state_dict()` / `load_state_dict()` use torch.optim.Adam's format so
+    optimizer checkpoints interchange with the reference.
+    """
+
+    def __init__(self, agent, group, named_params, lr):
+        self._agent, self._group = agent, group
+        self._names = [n for n, _ in named_params]
+        self._params = [p for _, p in named_params]
+        self.step_count = 0
+        self.defaults = dict(lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False,
+                             maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
+        self.param_groups = [dict(self.defaults, params=self._params, initial_lr=lr)]
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    def _moments(self):
+        eng = self._agent._engine
+        flat_m = eng.adam_m_vf if self._group == IqlEngine.GROUP_VF else eng.adam_m_pol
+        flat_v = eng.adam_v_vf if self._group == IqlEngine.GROUP_VF else eng.adam_v_pol
+        table = eng.tensor_table(self._group)
+        return IqlEngine.views(flat_m, table), IqlEngine.views(flat_v, table)
+
+    def zero_grad(self, set_to_none=True):
+        pass  # gradients are overwritten by every backward pass of the engine
+
+    def step(self):
+        raise RuntimeError("ArenaAdam steps inside the fused update (por_residual_update / update)")
+
+    def state_dict(self):
+        ms, vs = self._moments()
+        state = {}
+        if self.step_count > 0:
+            for i, (m, v) in enumerate(zip(ms, vs)):
+                state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=m.clone(), exp_avg_sq=v.clone())
+        groups = [{k: v for k, v in self.param_groups[0].items() if k != "params"}]
+        groups[0]["params"] = list(range(len(self._params)))
+        return dict(state=state, param_groups=groups)
+
+    def load_state_dict(self, sd):
+        ms, vs = self._moments()
+        steps = set()
+        with torch.no_grad():
+            for i, st in sd["state"].items():
+                ms[int(i)].copy_(st["exp_avg"])
+                vs[int(i)].copy_(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter Adam step counts differ; the flat sweep needs one counter")
+        self.step_count = steps.pop() if steps else 0
+        g = sd["param_groups"][0]
+        for k in ("lr", "betas", "eps", "initial_lr"):
+            if k in g:
+                self.param_groups[0][k] = g[k]
+
+
+class CosineSchedule:
+    """CosineAnnealingLR(T_max, eta_min=0) in closed form: equals torch's
+    recursive form to 2e-19, including the oscillation past T_max that the reference's runs exhibit."""
+
+    def __init__(self, optimizer: ArenaAdam, T_max):
+        self.optimizer, self.T_max, self.last_epoch = optimizer, T_max, 0
+        self.base_lrs = [optimizer.param_groups[0]["initial_lr"]]
+
+    def _lr(self, t):
+        return self.base_lrs[0] * (1.0 + math.cos(math.pi * t / self.T_max)) / 2.0
+
+    def step(self):
+        self.last_epoch += 1
+        self.optimizer.param_groups[0]["lr"] = self._lr(self.last_epoch)
+
+    def get_last_lr(self):
+        return [self.optimizer.param_groups[0]["lr"]]
+
+    def state_dict(self):
+        return dict(T_max=self.T_max, last_epoch=self.last_epoch, base_lrs=list(self.base_lrs))
+
+    def load_state_dict(self, sd):
+        self.T_max, self.last_epoch = sd["T_max"], sd["last_epoch"]
+        self.base_lrs = list(sd["base_lrs"])
+        self.optimizer.param_groups[0]["lr"] = self._lr(self.last_epoch)
+
+
+class IqlAgentBase(nn.Module):
+    """Owns the engine; subclasses set the module attribute names the reference uses."""
+
+    _warned_nll = False
+
+    def _setup_engine(self, vf: nn.Module, v_target: nn.Module, policy: nn.Module, *, obs_dim, pol_out_dim,
+                      hidden_dim, n_hidden, layer_norm, pol_tanh, weight_mode, device, max_batch):
+        self._engine = IqlEngine(obs_dim, pol_out_dim, hidden_dim, n_hidden, layer_norm, pol_tanh, weight_mode,
+                                 max_batch, device)
+        self._mods = (vf, v_target, policy)
+        self._adopt(copy_from_modules=True)
+        self._exchange = GradExchange()
+        self.async_losses = False     # True: return a (3,) device tensor instead of two host floats
+
+    def _adopt(self, copy_from_modules=False):
+        """Point every nn.Parameter at its view in the engine's flat tensors."""
+        eng = self._engine
+        vf, v_target, policy = self._mods
+        pairs = ((vf, eng.params_vf, IqlEngine.GROUP_VF, "vf"),
+                 (v_target, eng.params_tgt, IqlEngine.GROUP_VF, "target"),
+                 (policy, eng.params_pol, IqlEngine.GROUP_POL, "policy"))
+        with torch.no_grad():
+            for mod, flat, group, role in pairs:
+                views = IqlEngine.views(flat, eng.tensor_table(group))
+                params = list(mod.parameters())
+                if len(params) != len(views):
+                    raise RuntimeError(f"{role}: {len(params)} parameters vs {len(views)} engine tensors")
+                for p, v in zip(params, views):
+                    if tuple(p.shape) != tuple(v.shape):
+                        raise RuntimeError(f"{role}: parameter shape {tuple(p.shape)} vs engine {tuple(v.shape)}")
+                    if copy_from_modules:
+                        v.copy_(p)
+                    p.data = v
+                mod._engine, mod._engine_role, mod._private = eng, role, False
+        for p in v_target.parameters():
+            p.requires_grad_(False)
+
+    def _apply(self, fn, recurse=True):
+        # .to()/.cuda()/.cpu(): move the flat tensors, then re-create the parameter views
+        probe = fn(torch.empty(0, dtype=torch.float32, device=self._engine.device))
+        if probe.dtype != torch.float32:
+            raise RuntimeError("porl_amd agents are fp32 only")
+        self._engine.to(probe.device)
+        self.device = probe.device
+        self._adopt()
+        return self
+
+    # ---------------------------------------------------------------------------------------------
+    def _hyper(self, batch, v_opt: ArenaAdam, p_opt: ArenaAdam):
+        world = self._exchange.world_size
+        return self._engine.hyper(
+            tau=self.tau, discount=self.discount, alpha=self.alpha, ema_beta=self.beta,
+            inv_batch=1.0 / (batch * world), value_lr=v_opt.lr, policy_lr=p_opt.lr,
+            value_step=v_opt.step_count, policy_step=p_opt.step_count,
+            adam_beta1=v_opt.param_groups[0]["betas"][0], adam_beta2=v_opt.param_groups[0]["betas"][1],
+            adam_eps=v_opt.param_groups[0]["eps"])
+
+    def _full_update(self, obs, next_obs, rew, term, pol_target, v_opt, p_opt, sched):
+        eng, ex = self._engine, self._exchange
+        B = eng.load_batch(obs, next_obs, rew, term, pol_target)
+        v_opt.step_count += 1
+        p_opt.step_count += 1
+        hp = self._hyper(B, v_opt, p_opt)
+        if ex.world_size == 1:
+            eng.step(hp)
+        else:
+            # replay sharded across ranks: each rank's gradients carry 1/B_global, so SUM == global mean
+            eng.value_backward(hp)
+            ex.allreduce_sum_(eng.grads_vf)
+            eng.value_apply(hp)
+            eng.policy_backward(hp)
+            ex.allreduce_sum_(eng.grads_pol)
+            eng.policy_apply(hp)
+            ex.allreduce_stats_(eng.stats)
+        sched.step()
+        return self._losses()
+
+    def _value_update(self, obs, next_obs, rew, term, v_opt):
+        eng, ex = self._engine, self._exchange
+        B = eng.load_batch(obs, next_obs, rew, term, None)
+        v_opt.step_count += 1
+        hp = self._hyper(B, v_opt, v_opt)
+        eng.value_backward(hp)
+        if ex.world_size > 1:
+            ex.allreduce_sum_(eng.grads_vf)
+            ex.allreduce_stats_(eng.stats)
+        eng.value_apply(hp)
+
+    def _losses(self):
+        if self.async_losses:
+            return self._engine.stats[:3].clone()
+        v_loss, g_loss, min_nlp = self._engine.stats[:3].tolist()     # the one host sync of the update
+        if math.isnan(g_loss) or math.isnan(v_loss):
+            # the reference fails earlier (MultivariateNormal validate_args -> ValueError)
+            raise ValueError("NaN loss: non-finite values in the minibatch or the parameters")
+        if min_nlp <= 0 and not IqlAgentBase._warned_nll:
+            IqlAgentBase._warned_nll = True
+            warnings.warn("per-sample NLL <= 0 in this batch (the reference drops into pdb here, "
+                          "agent/por.py:104-105); continuing", RuntimeWarning)
+        self.last_min_nll = min_nlp
+        return v_loss, g_loss

@@ -1,0 +1,94 @@
+"""Diagonal-Gaussian policies with the reference's interface (/root/reference/agent/policy.py:12-73).
+
+`forward(obs)` computes the mean on the HIP engine and returns a light distribution object with the
+members the reference's callers use (`log_prob`, `mean`, `sample`; por.py:102-103, sorl.py:75,107-108).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from ..util.util import mlp
+from .value_functions import _EngineBacked
+
+LOG_STD_MIN = -5.0
+LOG_STD_MAX = 2.0
+
+
+class DiagGaussian:
+    """MultivariateNormal(mean, scale_tril=diag(std)) restricted to what the callers need."""
+
+    def __init__(self, mean, std):
+        self.mean, self.stddev = mean, std
+
+    def log_prob(self, value):
+        if torch.isnan(value).any():          # MultivariateNormal validate_args behaviour
+            raise ValueError("Expected value argument to be within the support of the distribution")
+        z = (value - self.mean) / self.stddev
+        d = self.mean.shape[-1]
+        return -0.5 * (d * math.log(2.0 * math.pi) + (z * z).sum(-1)) - torch.log(self.stddev).sum()
+
+    def sample(self):
+        with torch.no_grad():
+            return self.mean + self.stddev * torch.randn_like(self.mean)
+
+    rsample = sample
+
+
+class GaussianPolicy(_EngineBacked):
+    _tanh = False
+
+    def __init__(self, obs_dim, act_dim, hidden_dim=256, n_hidden=2):
+        super().__init__()
+        self.net = mlp([obs_dim, *([hidden_dim] * n_hidden), act_dim],
+                       output_activation=nn.Tanh if self._tanh else None)
+        self.log_std = nn.Parameter(torch.zeros(act_dim, dtype=torch.float32))
+        self._spec = (obs_dim, act_dim, hidden_dim, n_hidden)
+
+    def _attach_private(self, batch):
+        from ..engine import IqlEngine
+        S, D, H, L = self._spec
+        eng = self._private_engine(S, D, H, L, False, self._tanh, batch)
+        views = IqlEngine.views(eng.params_pol, eng.tensor_table(IqlEngine.GROUP_POL))
+        with torch.no_grad():
+            for p, v in zip(self.parameters(), views):      # log_std first, then net.* 
+                v.copy_(p)
+                p.data = v
+        self._engine, self._engine_role, self._private = eng, "policy", True
+
+    def forward(self, obs):
+        squeeze = obs.dim() == 1
+        if squeeze:
+            obs = obs.unsqueeze(0)
+        if self._engine is None or (self._private and self._engine.cfg.max_batch < obs.shape[0]):
+            self._attach_private(obs.shape[0])
+        mean = self._engine.forward_policy(obs)
+        if squeeze:
+            mean = mean[0]
+        std = torch.exp(self.log_std.detach().clamp(LOG_STD_MIN, LOG_STD_MAX))
+        return DiagGaussian(mean, std)
+
+    def act(self, obs, deterministic=False, enable_grad=False):
+        if enable_grad:
+            raise NotImplementedError("autograd through the HIP forward is not provided")
+        dist = self(obs)
+        return dist.mean if deterministic else dist.sample()
+
+
+class BoundedGaussianPolicy(GaussianPolicy):
+    """Tanh-squashed mean (reference policy.py:35-59).  The reference's |mean|>1 pdb trap is unreachable
+    (tanh) and is not reproduced."""
+    _tanh = True
+
+
+class DeterministicPolicy(nn.Module):
+    """Parameter container only (unused; reference policy.py:62-73)."""
+
+    def __init__(self, obs_dim, act_dim, hidden_dim=256, n_hidden=2):
+        super().__init__()
+        self.net = mlp([obs_dim, *([hidden_dim] * n_hidden), act_dim], output_activation=nn.Tanh)
+
+    def forward(self, obs):
+        raise NotImplementedError("DeterministicPolicy is not on the accelerated path")

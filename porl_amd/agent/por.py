@@ -1,0 +1,60 @@
+"""POR agent — drop-in for /root/reference/agent/por.py:20-112 on one MI355X.
+
+Same constructor, attributes (`goal_policy`, `vf`, `v_target`, `v_optimizer`, `goal_policy_optimizer`,
+`goal_lr_schedule`, `tau`, `alpha`, `discount`, `beta`), `state_dict()` keys and
+`por_residual_update(observations, next_observations, rewards, terminals) -> (v_loss, g_loss)`.
+All arithmetic of the update runs in hand-written gfx950 kernels (porl_amd/csrc); nothing here calls
+torch math on the device.
+
+Deliberate differences from the reference (SURVEY.md §8 notes 6):
+  * the `pdb.set_trace()` on NLL <= 0 (por.py:104-105) becomes a one-time RuntimeWarning;
+  * dead upstream code (`pretrain*`, `por_qlearning_update`, `save/load`) is not provided;
+  * `backbone` must be None (the image-encoder path is not part of this engine yet).
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+
+from ._iql import ArenaAdam, CosineSchedule, IqlAgentBase
+from .policy import GaussianPolicy
+from .value_functions import TwinV
+
+EXP_ADV_MAX = 100.
+
+
+class POR(IqlAgentBase):
+    def __init__(agent, args, max_steps, tau, alpha, backbone=None, device=torch.device('cpu'),
+                 value_lr=1e-4, policy_lr=1e-4, discount=0.99, beta=0.005):
+        super().__init__()
+        if backbone is not None:
+            raise NotImplementedError("POR(backbone=...) is outside the accelerated path")
+        agent.device = torch.device(device)
+        agent.backbone = None
+        # construction order fixes RNG consumption and state_dict order (por.py:36-45)
+        agent.goal_policy = GaussianPolicy(args.state_size, args.state_size,
+                                           hidden_dim=args.hidden_dim, n_hidden=args.n_hidden)
+        agent.vf = TwinV(args.state_size, layer_norm=args.layer_norm,
+                         hidden_dim=args.hidden_dim, n_hidden=args.n_hidden)
+        agent.v_target = copy.deepcopy(agent.vf).requires_grad_(False)
+        agent._setup_engine(agent.vf, agent.v_target, agent.goal_policy,
+                            obs_dim=args.state_size, pol_out_dim=args.state_size, hidden_dim=args.hidden_dim,
+                            n_hidden=args.n_hidden, layer_norm=args.layer_norm, pol_tanh=False, weight_mode=0,
+                            device=agent.device, max_batch=int(getattr(args, "max_batch", 0) or
+                                                               getattr(args, "batch_size", 0) or 1024))
+        agent.v_optimizer = ArenaAdam(agent, 0, list(agent.vf.named_parameters()), value_lr)
+        agent.goal_policy_optimizer = ArenaAdam(agent, 1, list(agent.goal_policy.named_parameters()), policy_lr)
+        agent.goal_lr_schedule = CosineSchedule(agent.goal_policy_optimizer, max_steps)
+        agent.tau = tau
+        agent.alpha = alpha
+        agent.discount = discount
+        agent.beta = beta
+        agent.step = 0
+        agent.pretrain_step = 0
+
+    def por_residual_update(agent, observations, next_observations, rewards, terminals):
+        """One POR gradient step (reference por.py:73-112): IQL value step, EMA target update, then the
+        advantage-weighted goal-policy regression on s'.  Returns (v_loss, g_loss) as Python floats."""
+        return agent._full_update(observations, next_observations, rewards, terminals, next_observations,
+                                  agent.v_optimizer, agent.goal_policy_optimizer, agent.goal_lr_schedule)

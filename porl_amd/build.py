@@ -1,0 +1,42 @@
+"""Build libporl_hip.so for gfx950 in-tree:  python -m porl_amd.build
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "porl_api.hip")
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("gemm_f32.hpp", "kernels.hpp")] + \
+       [os.path.join(os.path.dirname(HERE), "include", "porl_hip.h")]
+OUT = os.path.join(HERE, "lib", "libporl_hip.so")
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def up_to_date():
+    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
+
+
+def build(force=False, verbose=True):
+    if not force and up_to_date():
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

@@ -1,0 +1,428 @@
+// Non-GEMM kernels of the update step: batch packing, loss heads, reductions, Adam(+EMA) sweep, replay
+// gather.  All HBM/L2-bound or latency-bound; written for 64-wide wavefronts (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace porl {
+
+constexpr float LOG_STD_MIN = -5.0f;   // reference agent/policy.py:8-9
+constexpr float LOG_STD_MAX = 2.0f;
+constexpr float EXP_ADV_MAX = 100.0f;  // reference agent/por.py:12
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pack: strided caller tensors -> dense, zero-padded, 16-byte-aligned step buffers.
+// The reference hands the update column slices of one (B,row) tensor (por_train.py:74-78); s' starts
+// at float offset S+1, i.e. is only 4-byte aligned, so it cannot feed 16-byte loads directly.
+// ---------------------------------------------------------------------------------------------------
+struct PackJob {
+  const float* src; float* dst;
+  long src_row_stride;   // floats between rows
+  long src_col_stride;   // floats between columns (1 for matrices, unused for vectors)
+  int cols;              // valid columns
+  int ld;                // dst leading dimension (>= cols, padded with zeros)
+};
+struct PackArgs { int njobs; int rows; PackJob job[6]; };
+
+__global__ void pack_kernel(const PackArgs a) {
+  const PackJob& j = a.job[blockIdx.y];
+  const long n = (long)a.rows * j.ld;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / j.ld;
+    const int c = (int)(i - r * j.ld);
+    j.dst[i] = c < j.cols ? j.src[r * j.src_row_stride + (long)c * j.src_col_stride] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// IQL value head: v = sum(parts) + b; TD target; expectile loss and dL/dv   (agent/por.py:81-87)
+//   headparts layout: [net][part][B], nets = {target1, target2, online1, online2}
+// One block; deterministic reduction order.
+// ---------------------------------------------------------------------------------------------------
+struct ValueLossArgs {
+  const float* hp_t[2]; const float* hp_v[2];
+  const float* b_t[2]; const float* b_v[2];     // scalar output biases (device pointers)
+  const float* rew; const float* term;
+  float* target_v; float* dv[2];
+  float* stats;        // stats[0] = v_loss (this rank's share)
+  int B, parts;
+  float tau, discount, inv_batch;
+};
+
+__global__ __launch_bounds__(1024) void value_loss_kernel(const ValueLossArgs a) {
+  __shared__ float red[16];
+  float lsum = 0.f;
+  const float bt0 = a.b_t[0][0], bt1 = a.b_t[1][0], bv0 = a.b_v[0][0], bv1 = a.b_v[1][0];
+  for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
+    float t0 = 0.f, t1 = 0.f, v0 = 0.f, v1 = 0.f;
+    for (int p = 0; p < a.parts; ++p) {
+      const size_t o = (size_t)p * a.B + b;
+      t0 += a.hp_t[0][o]; t1 += a.hp_t[1][o]; v0 += a.hp_v[0][o]; v1 += a.hp_v[1][o];
+    }
+    t0 += bt0; t1 += bt1; v0 += bv0; v1 += bv1;
+    const float next_v = fminf(t0, t1);
+    const float tgt = a.rew[b] + (1.f - a.term[b]) * a.discount * next_v;
+    a.target_v[b] = tgt;
+    const float u0 = tgt - v0, u1 = tgt - v1;
+    const float w0 = fabsf(a.tau - (u0 < 0.f ? 1.f : 0.f)), w1 = fabsf(a.tau - (u1 < 0.f ? 1.f : 0.f));
+    lsum += 0.5f * (w0 * u0 * u0 + w1 * u1 * u1);
+    a.dv[0][b] = -w0 * u0 * a.inv_batch;
+    a.dv[1][b] = -w1 * u1 * a.inv_batch;
+  }
+  lsum = wave_sum(lsum);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) red[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    a.stats[0] = s * a.inv_batch;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// scalar-head weight gradient: dW[j] = sum_b dv[b] * H[b, j];  db = sum_b dv[b]
+// grid (ceil(H/64), nets), block 256 = 16 column-quads x 16 row lanes
+// ---------------------------------------------------------------------------------------------------
+struct HeadWgradArgs {
+  const float* H[2]; const float* dv[2]; float* dW[2]; float* db[2];
+  int B, Hdim, ld, nnets;
+};
+
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const HeadWgradArgs a) {
+  __shared__ float4 red[256];
+  const int net = blockIdx.y;
+  const float* __restrict__ Hm = a.H[net];
+  const float* __restrict__ dv = a.dv[net];
+  const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + c4 * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  float sb = 0.f;
+  const bool vec = (a.ld & 3) == 0 && col + 3 < a.Hdim;
+  for (int b = rl; b < a.B; b += 16) {
+    const float d = dv[b];
+    sb += d;
+    const float* p = Hm + (size_t)b * a.ld + col;
+    if (vec) {
+      const float4 h = *reinterpret_cast<const float4*>(p);
+      s.x += d * h.x; s.y += d * h.y; s.z += d * h.z; s.w += d * h.w;
+    } else {
+      if (col < a.Hdim) s.x += d * p[0];
+      if (col + 1 < a.Hdim) s.y += d * p[1];
+      if (col + 2 < a.Hdim) s.z += d * p[2];
+      if (col + 3 < a.Hdim) s.w += d * p[3];
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float4 t = red[threadIdx.x];
+    for (int r = 1; r < 16; ++r) {
+      const float4 o = red[r * 16 + threadIdx.x];
+      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    float* out = a.dW[net];
+    if (col < a.Hdim) out[col] = t.x;
+    if (col + 1 < a.Hdim) out[col + 1] = t.y;
+    if (col + 2 < a.Hdim) out[col + 2] = t.z;
+    if (col + 3 < a.Hdim) out[col + 3] = t.w;
+  }
+  if (blockIdx.x == 0) {   // bias gradient: threads with c4 == 0 hold disjoint row subsets
+    __syncthreads();
+    float* rf = reinterpret_cast<float*>(red);
+    if (c4 == 0) rf[rl] = sb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int r = 0; r < 16; ++r) t += rf[r];
+      a.db[net][0] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// advantage weight + diagonal-Gaussian NLL + its gradient   (agent/por.py:97-106, policy.py:18-23)
+//   one wave per row, lane j handles columns j, j+64, ...
+// ---------------------------------------------------------------------------------------------------
+struct PolicyNllArgs {
+  const float* hp_v[2]; const float* b_v[2]; int parts;   // updated twin V heads
+  const float* target_v;
+  const float* mean_slab; int nslab; long slab_stride;     // pre-bias mean = sum of split-K slabs
+  const float* mean_bias; const float* log_std;
+  const float* x; int ldx;                                 // regression target (s' or actions)
+  float* dmean; int ldd;                                   // dL/d(pre-activation mean), (B, ldd)
+  float* part_loss; float* part_min; float* part_dls;      // per-block partials; part_dls[blk][D]
+  int B, D, ldm;
+  int tanh_mean; int weight_mode;                          // 0: exp(adv/alpha), 1: exp(alpha*adv)
+  float alpha, inv_batch;
+  int rows_per_block;
+};
+
+constexpr int NLL_MAX_COLS_PER_LANE = 8;   // D <= 512
+
+__global__ __launch_bounds__(256) void policy_nll_kernel(const PolicyNllArgs a) {
+  __shared__ float sh_dls[4][NLL_MAX_COLS_PER_LANE * 64];
+  __shared__ float sh_loss[4], sh_min[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ncl = (a.D + 63) >> 6;
+  float sig[NLL_MAX_COLS_PER_LANE], isg[NLL_MAX_COLS_PER_LANE], mb[NLL_MAX_COLS_PER_LANE];
+  float dls[NLL_MAX_COLS_PER_LANE];
+  float lsig = 0.f;
+#pragma unroll
+  for (int c = 0; c < NLL_MAX_COLS_PER_LANE; ++c) {
+    const int j = lane + 64 * c;
+    sig[c] = 1.f; isg[c] = 1.f; mb[c] = 0.f; dls[c] = 0.f;
+    if (c < ncl && j < a.D) {
+      const float ls = fminf(fmaxf(a.log_std[j], LOG_STD_MIN), LOG_STD_MAX);
+      sig[c] = expf(ls);
+      isg[c] = 1.f / sig[c];
+      lsig += logf(sig[c]);               // the reference takes log(exp(.))
+      mb[c] = a.mean_bias[j];
+    }
+  }
+  lsig = wave_sum(lsig);
+  const float half_log2pi_D = 0.5f * (float)((double)a.D * 1.8378770664093454836);   // D*ln(2*pi)/2
+  const float bv0 = a.b_v[0][0], bv1 = a.b_v[1][0];
+  float loss_acc = 0.f, min_acc = INFINITY;
+  const int row0 = blockIdx.x * a.rows_per_block;
+  const int row1 = min(a.B, row0 + a.rows_per_block);
+  for (int b = row0 + wave; b < row1; b += 4) {
+    float v0 = 0.f, v1 = 0.f;
+    for (int p = 0; p < a.parts; ++p) {
+      v0 += a.hp_v[0][(size_t)p * a.B + b];
+      v1 += a.hp_v[1][(size_t)p * a.B + b];
+    }
+    const float adv = a.target_v[b] - fminf(v0 + bv0, v1 + bv1);
+    const float wgt = fminf(expf(a.weight_mode ? a.alpha * adv : adv / a.alpha), EXP_ADV_MAX);
+    const float wb = wgt * a.inv_batch;
+    float zz = 0.f;
+    float z[NLL_MAX_COLS_PER_LANE], mu[NLL_MAX_COLS_PER_LANE];
+#pragma unroll
+    for (int c = 0; c < NLL_MAX_COLS_PER_LANE; ++c) {
+      const int j = lane + 64 * c;
+      z[c] = 0.f; mu[c] = 0.f;
+      if (c < ncl && j < a.D) {
+        float m = a.mean_slab[(size_t)b * a.ldm + j];
+        for (int s = 1; s < a.nslab; ++s) m += a.mean_slab[(size_t)s * a.slab_stride + (size_t)b * a.ldm + j];
+        m += mb[c];
+        if (a.tanh_mean) m = tanhf(m);
+        mu[c] = m;
+        z[c] = (a.x[(size_t)b * a.ldx + j] - m) * isg[c];
+        zz += z[c] * z[c];
+      }
+    }
+    zz = wave_sum(zz);
+    const float nlp = half_log2pi_D + 0.5f * zz + lsig;
+    loss_acc += wb * nlp;
+    min_acc = fminf(min_acc, nlp);
+#pragma unroll
+    for (int c = 0; c < NLL_MAX_COLS_PER_LANE; ++c) {
+      const int j = lane + 64 * c;
+      if (c < ncl && j < a.D) {
+        float dm = -wb * z[c] * isg[c];
+        if (a.tanh_mean) dm *= (1.f - mu[c] * mu[c]);
+        a.dmean[(size_t)b * a.ldd + j] = dm;
+        dls[c] += wb * (1.f - z[c] * z[c]);
+      }
+    }
+  }
+  // zero the padding columns of dmean once per row (keeps the (B, ldd) buffer clean for 16-byte loads)
+  for (int b = row0 + wave; b < row1; b += 4)
+    for (int j = a.D + lane; j < a.ldd; j += 64) a.dmean[(size_t)b * a.ldd + j] = 0.f;
+
+#pragma unroll
+  for (int c = 0; c < NLL_MAX_COLS_PER_LANE; ++c) sh_dls[wave][c * 64 + lane] = dls[c];
+  if (lane == 0) { sh_loss[wave] = loss_acc; sh_min[wave] = min_acc; }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < NLL_MAX_COLS_PER_LANE; ++c) {
+      const int j = lane + 64 * c;
+      if (c < ncl && j < a.D)
+        a.part_dls[(size_t)blockIdx.x * a.D + j] =
+            sh_dls[0][c * 64 + lane] + sh_dls[1][c * 64 + lane] + sh_dls[2][c * 64 + lane] + sh_dls[3][c * 64 + lane];
+    }
+    if (lane == 0) {
+      a.part_loss[blockIdx.x] = sh_loss[0] + sh_loss[1] + sh_loss[2] + sh_loss[3];
+      a.part_min[blockIdx.x] = fminf(fminf(sh_min[0], sh_min[1]), fminf(sh_min[2], sh_min[3]));
+    }
+  }
+}
+
+// stats[1] = g_loss, stats[2] = min nlp, grad(log_std) — one block, fixed order
+__global__ __launch_bounds__(256) void policy_nll_finalize_kernel(const float* __restrict__ part_loss,
+                                                                   const float* __restrict__ part_min,
+                                                                   const float* __restrict__ part_dls, int nblk, int D,
+                                                                   const float* __restrict__ log_std,
+                                                                   float* __restrict__ g_log_std,
+                                                                   float* __restrict__ stats) {
+  for (int j = threadIdx.x; j < D; j += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += part_dls[(size_t)k * D + j];
+    const float ls = log_std[j];
+    g_log_std[j] = (ls >= LOG_STD_MIN && ls <= LOG_STD_MAX) ? s : 0.f;   // clamp passes no gradient outside
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f, m = INFINITY;
+    for (int k = 0; k < nblk; ++k) { s += part_loss[k]; m = fminf(m, part_min[k]); }
+    stats[1] = s;
+    stats[2] = m;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// torch.optim.Adam (single-tensor arithmetic) over a flat parameter group, with the
+// Polyak target update (util/util.py:54-56) fused in:  28 B/param (+8 B/param with the target).
+//   step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) are host doubles rounded to fp32.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        float* __restrict__ tgt, long n4, float omb1,
+                                                        float beta2, float omb2, float eps, float step_size,
+                                                        float bc2_sqrt, float ema_beta, float omeb) {
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  float4* t4 = reinterpret_cast<float4*>(tgt);
+  // omb1 = 1-beta1, omb2 = 1-beta2, omeb = 1-ema_beta are host doubles rounded once, like torch's scalars
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 pp = p4[i];
+    const float4 gg = g4[i];
+    float4 mm = m4[i], vv = v4[i];
+#define PORL_ADAM1(c)                                                     \
+    mm.c = mm.c + omb1 * (gg.c - mm.c);                                   \
+    vv.c = vv.c * beta2 + omb2 * gg.c * gg.c;                             \
+    pp.c = pp.c - step_size * (mm.c / (sqrtf(vv.c) / bc2_sqrt + eps));
+    PORL_ADAM1(x) PORL_ADAM1(y) PORL_ADAM1(z) PORL_ADAM1(w)
+#undef PORL_ADAM1
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    if (tgt) {
+      float4 tt = t4[i];
+      tt.x = tt.x * omeb + ema_beta * pp.x; tt.y = tt.y * omeb + ema_beta * pp.y;
+      tt.z = tt.z * omeb + ema_beta * pp.z; tt.w = tt.w * omeb + ema_beta * pp.w;
+      t4[i] = tt;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// split-K combine for several outputs in one launch: out = act(sum_s slab_s + bias)
+// ---------------------------------------------------------------------------------------------------
+struct ReduceJob {
+  float* out; const float* slab; const float* bias;
+  long n; long stride; int nslab; int ncols; int act;
+};
+struct ReduceArgs { int njobs; ReduceJob job[8]; };
+
+__global__ void multi_reduce_kernel(const ReduceArgs a) {
+  const ReduceJob& j = a.job[blockIdx.y];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < j.n; i += (long)gridDim.x * blockDim.x) {
+    float s = j.slab[i];
+    for (int k = 1; k < j.nslab; ++k) s += j.slab[(long)k * j.stride + i];
+    if (j.bias) s += j.bias[i % j.ncols];
+    if (j.act == 1) s = fmaxf(s, 0.f);
+    else if (j.act == 2) s = tanhf(s);
+    j.out[i] = s;
+  }
+}
+
+// v = sum(parts) + b for both twins (forward-only API: TwinV.both)
+__global__ void head_finish_kernel(const float* __restrict__ hp0, const float* __restrict__ hp1,
+                                   const float* __restrict__ b0, const float* __restrict__ b1, int parts, int B,
+                                   float* __restrict__ out0, float* __restrict__ out1) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float v0 = 0.f, v1 = 0.f;
+  for (int p = 0; p < parts; ++p) { v0 += hp0[(size_t)p * B + b]; v1 += hp1[(size_t)p * B + b]; }
+  out0[b] = v0 + b0[0];
+  out1[b] = v1 + b1[0];
+}
+
+// mean = act(sum of split-K slabs + bias), written to a caller view with arbitrary row stride
+__global__ void mean_finish_kernel(const float* __restrict__ slab, int nslab, long stride, int B, int D, int ldm,
+                                   const float* __restrict__ bias, int tanh_mean, float* __restrict__ out,
+                                   long out_rs) {
+  const long n = (long)B * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / D;
+    const int j = (int)(i - b * D);
+    float m = slab[b * ldm + j];
+    for (int s = 1; s < nslab; ++s) m += slab[(long)s * stride + b * ldm + j];
+    m += bias[j];
+    if (tanh_mean) m = tanhf(m);
+    out[b * out_rs + j] = m;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// replay gather: rows[idx[i], :] -> out[i, :]   (device-resident packed-row store, K12)
+// one wave per row; 16-byte lanes when the row width allows
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ rows, long row_stride,
+                                                           const int64_t* __restrict__ idx, int n, int width,
+                                                           float* __restrict__ out, long out_stride) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const bool vec = (width & 3) == 0 && (row_stride & 3) == 0 && (out_stride & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  for (int i = wave; i < n; i += nwaves) {
+    const float* src = rows + idx[i] * row_stride;
+    float* dst = out + (long)i * out_stride;
+    if (vec) {
+      for (int c = lane * 4; c < width; c += 256)
+        *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
+    } else {
+      for (int c = lane; c < width; c += 64) dst[c] = src[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// device sampler: `batch` DISTINCT row indices in [0, n) per call (uniform without replacement, like
+// np.random.choice(size, B, replace=False) in buffer/replay_buffer.py:64, but O(B) instead of O(N)):
+// index i is the image of i under a keyed pseudo-random permutation of [0, n) — a 4-round Feistel
+// network on 2*hb bits, cycle-walked into range.  Key = (seed, step).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+__global__ void sample_indices_kernel(int64_t n, int batch, uint64_t seed, uint64_t step, int hb,
+                                      int64_t base, int64_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  const uint32_t mask = (1u << hb) - 1u;
+  uint32_t keys[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    keys[r] = mix32((uint32_t)(seed >> (r & 1 ? 32 : 0)) ^ mix32((uint32_t)step * 4u + r) ^ (uint32_t)(step >> 30));
+  uint64_t x = (uint64_t)i;
+  for (int iter = 0; iter < 64; ++iter) {          // expected < 4 walks (domain < 4n); bounded regardless
+    uint32_t L = (uint32_t)(x >> hb) & mask, R = (uint32_t)x & mask;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t f = mix32(R ^ keys[r]) & mask;
+      const uint32_t t = L ^ f;
+      L = R; R = t;
+    }
+    x = ((uint64_t)L << hb) | R;
+    if ((int64_t)x < n) break;
+  }
+  if ((int64_t)x >= n) x = (uint64_t)i;              // unreachable in practice; keeps the index legal
+  out[i] = base + (int64_t)x;
+}
+
+}  // namespace porl

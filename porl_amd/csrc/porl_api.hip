@@ -1,0 +1,806 @@
+// libporl_hip.so — C ABI (include/porl_hip.h) over the gfx950 kernels.  Host-side planning only:
+// parameter/workspace layouts, the launch sequence of one update, and the group/tile/split-K choices
+// that keep 256 CUs busy with 1024-wide MLPs.  No device allocation, no synchronisation.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/porl_hip.h"
+#include "gemm_f32.hpp"
+#include "kernels.hpp"
+
+using namespace porl;
+
+namespace {
+
+thread_local std::string g_err;
+
+#define PORL_FAIL(code, ...)                         \
+  do {                                               \
+    char _b[512];                                    \
+    snprintf(_b, sizeof _b, __VA_ARGS__);            \
+    g_err = _b;                                      \
+    return (code);                                   \
+  } while (0)
+
+#define PORL_HIP(expr)                                                        \
+  do {                                                                        \
+    hipError_t _e = (expr);                                                   \
+    if (_e != hipSuccess) {                                                   \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(_e);              \
+      return (int)_e;                                                         \
+    }                                                                         \
+  } while (0)
+
+#define PORL_TRY(expr)          \
+  do {                          \
+    int _r = (expr);            \
+    if (_r != 0) return _r;     \
+  } while (0)
+
+// ---- optional per-launch timing with HIP events (bench.py's roofline leg) ---------------------------
+struct ProfRec { int label; hipEvent_t e0, e1; double flops, bytes; };
+struct ProfState {
+  bool on = false;
+  std::vector<std::string> labels;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  size_t pool_used = 0;
+  hipEvent_t get() {
+    if (pool_used == pool.size()) { hipEvent_t e; hipEventCreate(&e); pool.push_back(e); }
+    return pool[pool_used++];
+  }
+  int label_id(const std::string& s) {
+    for (size_t i = 0; i < labels.size(); ++i) if (labels[i] == s) return (int)i;
+    labels.push_back(s);
+    return (int)labels.size() - 1;
+  }
+} g_prof;
+
+struct ProfScope {
+  bool active; ProfRec r; hipStream_t s;
+  ProfScope(const std::string& label, hipStream_t st, double flops, double bytes) : active(g_prof.on), s(st) {
+    if (!active) return;
+    r.label = g_prof.label_id(label); r.flops = flops; r.bytes = bytes;
+    r.e0 = g_prof.get(); r.e1 = g_prof.get();
+    hipEventRecord(r.e0, s);
+  }
+  ~ProfScope() {
+    if (!active) return;
+    hipEventRecord(r.e1, s);
+    g_prof.recs.push_back(r);
+  }
+};
+
+constexpr int NUM_CU = 256;
+constexpr int SK_MAX = 16;
+constexpr int NLL_ROWS_PER_BLOCK = 16;
+
+inline int64_t ru4(int64_t x) { return (x + 3) & ~int64_t(3); }
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+struct TensorInfo { int64_t off; int rows, cols; };
+
+struct MlpLayout {
+  int n_lin = 0;                       // Linear layers = n_hidden + 1
+  int dims[PORL_MAX_HIDDEN + 2] = {0};
+  int64_t w[PORL_MAX_HIDDEN + 1] = {0}, b[PORL_MAX_HIDDEN + 1] = {0};
+  int64_t lnw[PORL_MAX_HIDDEN] = {0}, lnb[PORL_MAX_HIDDEN] = {0};
+  bool ln = false;
+};
+
+int64_t add_tensor(std::vector<TensorInfo>& v, int64_t& cur, int rows, int cols) {
+  const int64_t off = cur;
+  v.push_back({off, rows, cols});
+  cur += ru4((int64_t)(rows ? rows : 1) * cols);
+  return off;
+}
+
+// named_parameters() order of util.mlp: Linear(w,b) [LayerNorm(w,b)] per hidden layer, final Linear
+void layout_mlp(MlpLayout& m, std::vector<TensorInfo>& v, int64_t& cur, int in, int hid, int L, int out, bool ln) {
+  m.n_lin = L + 1;
+  m.ln = ln;
+  m.dims[0] = in;
+  for (int l = 0; l < L; ++l) m.dims[l + 1] = hid;
+  m.dims[L + 1] = out;
+  for (int l = 0; l <= L; ++l) {
+    m.w[l] = add_tensor(v, cur, m.dims[l + 1], m.dims[l]);
+    m.b[l] = add_tensor(v, cur, 0, m.dims[l + 1]);
+    if (ln && l < L) {
+      m.lnw[l] = add_tensor(v, cur, 0, hid);
+      m.lnb[l] = add_tensor(v, cur, 0, hid);
+    }
+  }
+}
+
+struct Workspace {
+  int64_t xs, xn, xt, rew, term;
+  int64_t act_v[2][PORL_MAX_HIDDEN], act_t[2][2], act_p[PORL_MAX_HIDDEN];
+  int64_t dz_v[2][2], dz_p[2];
+  int64_t hp_t[2], hp_v[2];
+  int64_t target_v, dv[2], dmu;
+  int64_t slab_mean, slab_a, slab_b;
+  int64_t part_loss, part_min, part_dls;
+  int64_t total;
+};
+
+}  // namespace
+
+struct porl_iql {
+  porl_iql_cfg cfg;
+  MlpLayout v[2], pol;
+  int64_t logstd_off = 0, n_vf = 0, n_pol = 0;
+  std::vector<TensorInfo> t_vf, t_pol;
+  porl_iql_buffers buf{};
+  bool bound = false;
+  int batch = 0;
+  bool have_pol_target = false;
+  int Sp = 0, Dp = 0, Hp = 0, parts_max = 0;
+  Workspace ws{};
+};
+
+namespace {
+
+// ---- launch helpers -------------------------------------------------------------------------------
+int pick_tile(const GemmGroup& g) {
+  int minM = 1 << 30, minN = 1 << 30;
+  for (int i = 0; i < g.nprob; ++i) { minM = std::min(minM, g.p[i].M); minN = std::min(minN, g.p[i].N); }
+  auto blocks = [&](int tile) {
+    int bm, bn, n = 0;
+    tile_dims(tile, bm, bn);
+    for (int i = 0; i < g.nprob; ++i) n += cdiv(g.p[i].M, bm) * cdiv(g.p[i].N, bn) * std::max(1, g.p[i].splitk);
+    return n;
+  };
+  int cand[3], nc = 0;
+  if (minN <= 64 && minM <= 64) { cand[nc++] = TILE_64x64; }
+  else if (minN <= 64) { cand[nc++] = TILE_128x64; cand[nc++] = TILE_64x64; }
+  else if (minM <= 64) { cand[nc++] = TILE_64x128; cand[nc++] = TILE_64x64; }
+  else { cand[nc++] = TILE_128x128; cand[nc++] = TILE_128x64; cand[nc++] = TILE_64x64; }
+  for (int i = 0; i < nc; ++i)
+    if (blocks(cand[i]) >= NUM_CU) return cand[i];
+  return cand[nc - 1];
+}
+
+// split-K factor for an output too small to fill the chip on its own
+int pick_splitk(int M, int N, int K, int nprob, int bm, int bn) {
+  const int tiles = nprob * cdiv(M, bm) * cdiv(N, bn);
+  int sk = cdiv(NUM_CU, tiles);
+  sk = std::min(sk, std::max(1, K / 64));
+  return std::max(1, std::min(sk, SK_MAX));
+}
+
+int launch_group(GemmGroup& g, int tile, hipStream_t s) {
+  double flops = 0.0, bytes = 0.0;
+  std::string label;
+  if (g_prof.on) {
+    bool vec = true, apro = false;
+    for (int i = 0; i < g.nprob; ++i) {
+      const GemmProb& p = g.p[i];
+      flops += 2.0 * p.M * p.N * p.K;
+      bytes += 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (p.store_c ? (double)p.M * p.N : 0.0));
+      vec = vec && p.a_vec && p.b_vec;
+      apro = apro || p.apro != APRO_NONE;
+    }
+    int bm, bn;
+    tile_dims(tile, bm, bn);
+    label = "gemm_f32_kernel<" + std::to_string(bm) + "," + std::to_string(bn) + ",16," + (vec ? "true" : "false") +
+            "," + (apro ? "true" : "false") + ">";
+  }
+  ProfScope ps(label, s, flops, bytes);
+  hipError_t e = launch_gemm_group(tile, g, s);
+  if (e != hipSuccess) {
+    g_err = std::string("gemm launch: ") + hipGetErrorString(e);
+    return (int)e;
+  }
+  return 0;
+}
+
+int launch_reduce(ReduceArgs& r, hipStream_t s) {
+  if (r.njobs == 0) return 0;
+  long maxn = 0;
+  for (int i = 0; i < r.njobs; ++i) maxn = std::max(maxn, r.job[i].n);
+  dim3 grid((unsigned)std::min<long>((maxn + 255) / 256, 512), r.njobs);
+  hipLaunchKernelGGL(multi_reduce_kernel, grid, dim3(256), 0, s, r);
+  PORL_HIP(hipGetLastError());
+  return 0;
+}
+
+void add_reduce(ReduceArgs& r, float* out, const float* slab, long n, long stride, int nslab) {
+  ReduceJob& j = r.job[r.njobs++];
+  j.out = out; j.slab = slab; j.bias = nullptr; j.n = n; j.stride = stride; j.nslab = nslab; j.ncols = 1; j.act = 0;
+}
+
+int check_ready(const porl_iql* h, bool need_batch) {
+  if (!h) PORL_FAIL(PORL_ERR_INVALID, "null engine");
+  if (!h->bound) PORL_FAIL(PORL_ERR_UNBOUND, "porl_iql_bind() has not been called");
+  if (need_batch && h->batch <= 0) PORL_FAIL(PORL_ERR_INVALID, "no minibatch loaded (porl_iql_load_batch)");
+  return 0;
+}
+
+// One hidden layer of up to 4 MLPs as one grouped launch.
+struct FwdNet {
+  const float* in; int ldin;       // (B, K)
+  const float* W; const float* b;  // (H, K), (H)
+  float* out;                      // (B, Hp) or null when only the head is needed
+  const float* headw; float* headout;
+};
+
+int fwd_hidden_layer(porl_iql* h, const FwdNet* nets, int nnets, int B, int K, bool last, int* parts_out,
+                     hipStream_t s) {
+  const int H = h->cfg.hidden_dim;
+  GemmGroup g{};
+  g.nprob = nnets;
+  for (int n = 0; n < nnets; ++n) {
+    GemmProb p = make_prob(GEMM_NT, nets[n].in, nets[n].ldin, nets[n].W, K, nets[n].out, h->Hp, B, H, K);
+    p.bias = nets[n].b;
+    p.act = ACT_RELU;
+    p.store_c = nets[n].out != nullptr;
+    if (last && nets[n].headw) { p.headw = nets[n].headw; p.headout = nets[n].headout; }
+    g.p[n] = p;
+  }
+  const int tile = pick_tile(g);
+  if (parts_out) *parts_out = head_parts(H, tile);
+  return launch_group(g, tile, s);
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int porl_abi_version(void) { return PORL_ABI_VERSION; }
+const char* porl_last_error(void) { return g_err.c_str(); }
+
+int porl_iql_create(const porl_iql_cfg* c, porl_iql** out) {
+  if (!c || !out) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  if (c->obs_dim < 1 || c->pol_out_dim < 1 || c->hidden_dim < 1 || c->max_batch < 1)
+    PORL_FAIL(PORL_ERR_INVALID, "dimensions must be positive");
+  if (c->n_hidden < 1 || c->n_hidden > PORL_MAX_HIDDEN) PORL_FAIL(PORL_ERR_INVALID, "n_hidden must be in [1,%d]", PORL_MAX_HIDDEN);
+  if (c->pol_out_dim > 64 * NLL_MAX_COLS_PER_LANE) PORL_FAIL(PORL_ERR_UNSUPPORTED, "pol_out_dim > %d", 64 * NLL_MAX_COLS_PER_LANE);
+  if (c->layer_norm) PORL_FAIL(PORL_ERR_UNSUPPORTED, "layer_norm=True is not implemented on device yet");
+  porl_iql* h = new porl_iql();
+  h->cfg = *c;
+  const int S = c->obs_dim, D = c->pol_out_dim, H = c->hidden_dim, L = c->n_hidden, B = c->max_batch;
+  int64_t cur = 0;
+  layout_mlp(h->v[0], h->t_vf, cur, S, H, L, 1, c->layer_norm != 0);
+  layout_mlp(h->v[1], h->t_vf, cur, S, H, L, 1, c->layer_norm != 0);
+  h->n_vf = cur;
+  cur = 0;
+  h->logstd_off = add_tensor(h->t_pol, cur, 0, D);
+  layout_mlp(h->pol, h->t_pol, cur, S, H, L, D, false);
+  h->n_pol = cur;
+
+  h->Sp = (int)ru4(S); h->Dp = (int)ru4(D); h->Hp = (int)ru4(H);
+  h->parts_max = cdiv(H, 64) * 2;
+  Workspace& w = h->ws;
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += ru4(n); return r; };
+  const int64_t BH = (int64_t)B * h->Hp;
+  w.xs = take((int64_t)B * h->Sp); w.xn = take((int64_t)B * h->Sp); w.xt = take((int64_t)B * h->Dp);
+  w.rew = take(B); w.term = take(B);
+  for (int i = 0; i < 2; ++i) {
+    for (int l = 0; l < L; ++l) w.act_v[i][l] = take(BH);
+    w.act_t[i][0] = take(BH); w.act_t[i][1] = take(BH);
+    w.dz_v[i][0] = take(BH); w.dz_v[i][1] = take(BH);
+    w.hp_t[i] = take((int64_t)h->parts_max * B); w.hp_v[i] = take((int64_t)h->parts_max * B);
+    w.dv[i] = take(B);
+  }
+  for (int l = 0; l < L; ++l) w.act_p[l] = take(BH);
+  w.dz_p[0] = take(BH); w.dz_p[1] = take(BH);
+  w.target_v = take(B);
+  w.dmu = take((int64_t)B * h->Dp);
+  w.slab_mean = take((int64_t)SK_MAX * B * h->Dp);
+  w.slab_a = take((int64_t)SK_MAX * 2 * ((int64_t)H * S + H + 8));
+  w.slab_b = take((int64_t)SK_MAX * ((int64_t)D * H + D + 8));
+  const int nblk = cdiv(B, NLL_ROWS_PER_BLOCK);
+  w.part_loss = take(nblk); w.part_min = take(nblk); w.part_dls = take((int64_t)nblk * D);
+  w.total = o;
+  *out = h;
+  return PORL_OK;
+}
+
+void porl_iql_destroy(porl_iql* h) { delete h; }
+
+int64_t porl_iql_group_floats(const porl_iql* h, int group) { return !h ? 0 : (group == 0 ? h->n_vf : h->n_pol); }
+int32_t porl_iql_group_tensors(const porl_iql* h, int group) {
+  return !h ? 0 : (int32_t)(group == 0 ? h->t_vf.size() : h->t_pol.size());
+}
+int porl_iql_tensor_info(const porl_iql* h, int group, int index, int64_t* offset, int32_t* rows, int32_t* cols) {
+  if (!h || group < 0 || group > 1) PORL_FAIL(PORL_ERR_INVALID, "bad group");
+  const auto& v = group == 0 ? h->t_vf : h->t_pol;
+  if (index < 0 || index >= (int)v.size()) PORL_FAIL(PORL_ERR_INVALID, "tensor index out of range");
+  if (offset) *offset = v[index].off;
+  if (rows) *rows = v[index].rows;
+  if (cols) *cols = v[index].cols;
+  return PORL_OK;
+}
+int64_t porl_iql_workspace_floats(const porl_iql* h) { return h ? h->ws.total : 0; }
+
+int porl_iql_bind(porl_iql* h, const porl_iql_buffers* b) {
+  if (!h || !b) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  const void* ptrs[] = {b->params_vf, b->params_tgt, b->params_pol, b->grads_vf, b->grads_pol, b->adam_m_vf,
+                        b->adam_v_vf, b->adam_m_pol, b->adam_v_pol, b->workspace, b->stats};
+  for (const void* p : ptrs) {
+    if (!p) PORL_FAIL(PORL_ERR_INVALID, "null buffer");
+    if (!aligned16(p)) PORL_FAIL(PORL_ERR_INVALID, "buffers must be 16-byte aligned");
+  }
+  h->buf = *b;
+  h->bound = true;
+  h->batch = 0;
+  return PORL_OK;
+}
+
+int porl_iql_load_batch(porl_iql* h, int32_t batch, const float* obs, int64_t obs_rs, const float* next_obs,
+                        int64_t next_rs, const float* rew, int64_t rew_rs, const float* term, int64_t term_rs,
+                        const float* pol_target, int64_t pt_rs, void* stream) {
+  PORL_TRY(check_ready(h, false));
+  if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
+  if (!obs || !next_obs || !rew || !term) PORL_FAIL(PORL_ERR_INVALID, "null batch tensor");
+  float* W = h->buf.workspace;
+  PackArgs a{};
+  a.rows = batch;
+  auto job = [&](const float* src, int64_t rs, float* dst, int cols, int ld) {
+    PackJob& j = a.job[a.njobs++];
+    j.src = src; j.dst = dst; j.src_row_stride = rs; j.src_col_stride = 1; j.cols = cols; j.ld = ld;
+  };
+  job(obs, obs_rs, W + h->ws.xs, h->cfg.obs_dim, h->Sp);
+  job(next_obs, next_rs, W + h->ws.xn, h->cfg.obs_dim, h->Sp);
+  job(rew, rew_rs, W + h->ws.rew, 1, 1);
+  job(term, term_rs, W + h->ws.term, 1, 1);
+  if (pol_target) job(pol_target, pt_rs, W + h->ws.xt, h->cfg.pol_out_dim, h->Dp);
+  h->have_pol_target = pol_target != nullptr;
+  const long n = (long)batch * std::max(h->Sp, h->Dp);
+  dim3 grid((unsigned)std::min<long>((n + 255) / 256, 1024), a.njobs);
+  hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  PORL_HIP(hipGetLastError());
+  h->batch = batch;
+  return PORL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
+  PORL_TRY(check_ready(h, true));
+  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+  hipStream_t s = (hipStream_t)stream;
+  const int B = h->batch, S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden, Hp = h->Hp;
+  float* W = h->buf.workspace;
+  const Workspace& ws = h->ws;
+  const float* Pv = h->buf.params_vf;
+  const float* Pt = h->buf.params_tgt;
+  float* Gv = h->buf.grads_vf;
+  int parts = 0;
+
+  // -- forward: target twins on s', online twins on s — 4 nets per launch ---------------------------
+  for (int l = 0; l < L; ++l) {
+    FwdNet nets[4];
+    const int K = l == 0 ? S : H;
+    for (int n = 0; n < 4; ++n) {
+      const bool tgt = n < 2;
+      const int i = n & 1;
+      const float* P = tgt ? Pt : Pv;
+      FwdNet& f = nets[n];
+      if (l == 0) { f.in = W + (tgt ? ws.xn : ws.xs); f.ldin = h->Sp; }
+      else { f.in = W + (tgt ? ws.act_t[i][(l - 1) & 1] : ws.act_v[i][l - 1]); f.ldin = Hp; }
+      f.W = P + h->v[i].w[l]; f.b = P + h->v[i].b[l];
+      const bool last = l == L - 1;
+      f.out = tgt ? (last ? nullptr : W + ws.act_t[i][l & 1]) : W + ws.act_v[i][l];
+      f.headw = P + h->v[i].w[L];
+      f.headout = W + (tgt ? ws.hp_t[i] : ws.hp_v[i]);
+    }
+    PORL_TRY(fwd_hidden_layer(h, nets, 4, B, K, l == L - 1, &parts, s));
+  }
+
+  // -- TD target, expectile loss, dL/dv -----------------------------------------------------------------
+  {
+    ValueLossArgs a{};
+    for (int i = 0; i < 2; ++i) {
+      a.hp_t[i] = W + ws.hp_t[i]; a.hp_v[i] = W + ws.hp_v[i];
+      a.b_t[i] = Pt + h->v[i].b[L]; a.b_v[i] = Pv + h->v[i].b[L];
+      a.dv[i] = W + ws.dv[i];
+    }
+    a.rew = W + ws.rew; a.term = W + ws.term; a.target_v = W + ws.target_v; a.stats = h->buf.stats;
+    a.B = B; a.parts = parts; a.tau = hp->tau; a.discount = hp->discount; a.inv_batch = hp->inv_batch;
+    hipLaunchKernelGGL(value_loss_kernel, dim3(1), dim3(1024), 0, s, a);
+    PORL_HIP(hipGetLastError());
+  }
+
+  // -- output layer gradient: dW_L = dv^T H_{L-1}, db_L = sum dv ------------------------------------------
+  {
+    HeadWgradArgs a{};
+    for (int i = 0; i < 2; ++i) {
+      a.H[i] = W + ws.act_v[i][L - 1]; a.dv[i] = W + ws.dv[i];
+      a.dW[i] = Gv + h->v[i].w[L]; a.db[i] = Gv + h->v[i].b[L];
+    }
+    a.B = B; a.Hdim = H; a.ld = Hp; a.nnets = 2;
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3(cdiv(H, 64), 2), dim3(256), 0, s, a);
+    PORL_HIP(hipGetLastError());
+  }
+
+  // -- hidden layers, top down.  dZ of the top layer is never materialised: it is the rank-1 prologue
+  //    dv[b] * w_L[j] * 1[H_{L-1}[b,j] > 0] applied while staging H_{L-1}. ----------------------------
+  ReduceArgs red{};
+  for (int l = L - 1; l >= 0; --l) {
+    const bool top = l == L - 1;
+    const int Kin = l == 0 ? S : H;
+    GemmGroup g{};
+    for (int i = 0; i < 2; ++i) {
+      const float* dz = top ? W + ws.act_v[i][L - 1] : W + ws.dz_v[i][l & 1];
+      const float* in = l == 0 ? W + ws.xs : W + ws.act_v[i][l - 1];
+      const int ldin = l == 0 ? h->Sp : Hp;
+      GemmProb p = make_prob(GEMM_TN, dz, Hp, in, ldin, Gv + h->v[i].w[l], Kin, H, Kin, B);
+      p.colsum = Gv + h->v[i].b[l];
+      if (top) { p.apro = APRO_RANK1_MASK; p.a_rowscale = W + ws.dv[i]; p.a_colscale = Pv + h->v[i].w[L]; }
+      g.p[g.nprob++] = p;
+      if (l > 0) {
+        GemmProb q = make_prob(GEMM_NN, dz, Hp, Pv + h->v[i].w[l], Kin, W + ws.dz_v[i][(l - 1) & 1], Hp, B, Kin, H);
+        q.mask = W + ws.act_v[i][l - 1]; q.ldmask = Hp;
+        if (top) { q.apro = APRO_RANK1_MASK; q.a_rowscale = W + ws.dv[i]; q.a_colscale = Pv + h->v[i].w[L]; }
+        g.p[g.nprob++] = q;
+      }
+    }
+    int tile = pick_tile(g);
+    if (l == 0) {
+      // skinny (H x S) weight gradient: split the batch (K) dimension to fill the chip
+      int bm, bn;
+      tile_dims(tile, bm, bn);
+      const int sk = pick_splitk(H, Kin, B, 2, bm, bn);
+      if (sk > 1) {
+        const int64_t per = (int64_t)H * Kin, perc = H;
+        for (int i = 0; i < 2; ++i) {
+          float* slabW = W + ws.slab_a + (int64_t)i * SK_MAX * (per + perc + 8);
+          float* slabC = slabW + (int64_t)SK_MAX * per;
+          g.p[i].splitk = sk; g.p[i].C = slabW; g.p[i].colsum = slabC;
+          add_reduce(red, Gv + h->v[i].w[0], slabW, per, per, sk);
+          add_reduce(red, Gv + h->v[i].b[0], slabC, perc, perc, sk);
+        }
+      }
+    }
+    PORL_TRY(launch_group(g, tile, s));
+  }
+  PORL_TRY(launch_reduce(red, s));
+  return PORL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+static int adam_launch(float* p, const float* g, float* m, float* v, float* tgt, int64_t n, float lr, int step,
+                       float b1, float b2, float eps, float ema_beta, hipStream_t s) {
+  if (n % 4) PORL_FAIL(PORL_ERR_INVALID, "adam range must be a multiple of 4 floats");
+  if (step < 1) PORL_FAIL(PORL_ERR_INVALID, "adam step must be >= 1");
+  // torch._single_tensor_adam: python doubles, rounded to fp32 where they meet tensors
+  const double bc1 = 1.0 - std::pow((double)b1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)b2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)std::sqrt(bc2);
+  const float omb1 = (float)(1.0 - (double)b1), omb2 = (float)(1.0 - (double)b2);
+  const float omeb = (float)(1.0 - (double)ema_beta);
+  const long n4 = n / 4;
+  const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 2048);
+  ProfScope ps("adam_ema_kernel", s, 0.0, (double)n * (tgt ? 36.0 : 28.0));
+  hipLaunchKernelGGL(adam_ema_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, tgt, n4, omb1, b2, omb2, eps,
+                     step_size, bc2_sqrt, ema_beta, omeb);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_iql_value_apply(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
+  PORL_TRY(check_ready(h, false));
+  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+  return adam_launch(h->buf.params_vf, h->buf.grads_vf, h->buf.adam_m_vf, h->buf.adam_v_vf, h->buf.params_tgt,
+                     h->n_vf, hp->value_lr, hp->value_step, hp->adam_beta1, hp->adam_beta2, hp->adam_eps,
+                     hp->ema_beta, (hipStream_t)stream);
+}
+
+int porl_iql_policy_apply(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
+  PORL_TRY(check_ready(h, false));
+  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+  return adam_launch(h->buf.params_pol, h->buf.grads_pol, h->buf.adam_m_pol, h->buf.adam_v_pol, nullptr, h->n_pol,
+                     hp->policy_lr, hp->policy_step, hp->adam_beta1, hp->adam_beta2, hp->adam_eps, 0.f,
+                     (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// policy mean (pre-bias, pre-activation) as split-K slabs: act_p[L-1] (B,H) x W_L^T (H,D)
+static int policy_mean_slabs(porl_iql* h, int B, int* nslab, hipStream_t s) {
+  const int H = h->cfg.hidden_dim, D = h->cfg.pol_out_dim, L = h->cfg.n_hidden;
+  float* W = h->buf.workspace;
+  GemmGroup g{};
+  g.nprob = 1;
+  g.p[0] = make_prob(GEMM_NT, W + h->ws.act_p[L - 1], h->Hp, h->buf.params_pol + h->pol.w[L], H, W + h->ws.slab_mean,
+                     h->Dp, B, D, H);
+  const int tile = pick_tile(g);
+  int bm, bn;
+  tile_dims(tile, bm, bn);
+  const int sk = pick_splitk(B, D, H, 1, bm, bn);
+  // splitk == 1 still writes the raw product (bias and tanh are applied by the consumer)
+  g.p[0].splitk = sk;
+  *nslab = sk;
+  if (sk == 1) { g.p[0].bias = nullptr; g.p[0].act = ACT_NONE; }
+  return launch_group(g, tile, s);
+}
+
+int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
+  PORL_TRY(check_ready(h, true));
+  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+  if (!h->have_pol_target) PORL_FAIL(PORL_ERR_INVALID, "policy step needs pol_target in porl_iql_load_batch");
+  hipStream_t s = (hipStream_t)stream;
+  const int B = h->batch, S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden, D = h->cfg.pol_out_dim;
+  const int Hp = h->Hp, Dp = h->Dp;
+  float* W = h->buf.workspace;
+  const Workspace& ws = h->ws;
+  const float* Pv = h->buf.params_vf;
+  const float* Pp = h->buf.params_pol;
+  float* Gp = h->buf.grads_pol;
+  int parts = 0;
+
+  // -- forward: updated twins (head only) + policy hidden layers, 3 nets per launch ----------------
+  for (int l = 0; l < L; ++l) {
+    FwdNet nets[3];
+    const int K = l == 0 ? S : H;
+    const bool last = l == L - 1;
+    for (int i = 0; i < 2; ++i) {
+      FwdNet& f = nets[i];
+      if (l == 0) { f.in = W + ws.xs; f.ldin = h->Sp; }
+      else { f.in = W + ws.act_t[i][(l - 1) & 1]; f.ldin = Hp; }       // target scratch is free now
+      f.W = Pv + h->v[i].w[l]; f.b = Pv + h->v[i].b[l];
+      f.out = last ? nullptr : W + ws.act_t[i][l & 1];
+      f.headw = Pv + h->v[i].w[L]; f.headout = W + ws.hp_v[i];
+    }
+    FwdNet& f = nets[2];
+    if (l == 0) { f.in = W + ws.xs; f.ldin = h->Sp; }
+    else { f.in = W + ws.act_p[l - 1]; f.ldin = Hp; }
+    f.W = Pp + h->pol.w[l]; f.b = Pp + h->pol.b[l];
+    f.out = W + ws.act_p[l]; f.headw = nullptr; f.headout = nullptr;
+    PORL_TRY(fwd_hidden_layer(h, nets, 3, B, K, last, &parts, s));
+  }
+  int nslab = 1;
+  PORL_TRY(policy_mean_slabs(h, B, &nslab, s));
+
+  // -- advantage weights, NLL, dL/dmean, dL/dlog_std --------------------------------------------------
+  const int nblk = cdiv(B, NLL_ROWS_PER_BLOCK);
+  {
+    PolicyNllArgs a{};
+    for (int i = 0; i < 2; ++i) { a.hp_v[i] = W + ws.hp_v[i]; a.b_v[i] = Pv + h->v[i].b[L]; }
+    a.parts = parts; a.target_v = W + ws.target_v;
+    a.mean_slab = W + ws.slab_mean; a.nslab = nslab; a.slab_stride = (long)B * Dp;
+    a.mean_bias = Pp + h->pol.b[L]; a.log_std = Pp + h->logstd_off;
+    a.x = W + ws.xt; a.ldx = Dp; a.dmean = W + ws.dmu; a.ldd = Dp;
+    a.part_loss = W + ws.part_loss; a.part_min = W + ws.part_min; a.part_dls = W + ws.part_dls;
+    a.B = B; a.D = D; a.ldm = Dp; a.tanh_mean = h->cfg.pol_tanh; a.weight_mode = h->cfg.weight_mode;
+    a.alpha = hp->alpha; a.inv_batch = hp->inv_batch; a.rows_per_block = NLL_ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(policy_nll_kernel, dim3(nblk), dim3(256), 0, s, a);
+    PORL_HIP(hipGetLastError());
+    hipLaunchKernelGGL(policy_nll_finalize_kernel, dim3(1), dim3(256), 0, s, W + ws.part_loss, W + ws.part_min,
+                       W + ws.part_dls, nblk, D, Pp + h->logstd_off, Gp + h->logstd_off, h->buf.stats);
+    PORL_HIP(hipGetLastError());
+  }
+
+  // -- backward ---------------------------------------------------------------------------------------
+  ReduceArgs red{};
+  {
+    // output layer: dW_L = dmu^T H_{L-1} (D x H, skinny M), and dZ_{L-1} = (dmu W_L) . 1[H_{L-1} > 0]
+    GemmGroup g{};
+    g.nprob = 2;
+    g.p[0] = make_prob(GEMM_TN, W + ws.dmu, Dp, W + ws.act_p[L - 1], Hp, Gp + h->pol.w[L], H, D, H, B);
+    g.p[0].colsum = Gp + h->pol.b[L];
+    g.p[1] = make_prob(GEMM_NN, W + ws.dmu, Dp, Pp + h->pol.w[L], H, W + ws.dz_p[(L - 1) & 1], Hp, B, H, D);
+    g.p[1].mask = W + ws.act_p[L - 1]; g.p[1].ldmask = Hp;
+    const int tile = D <= 64 ? TILE_64x128 : pick_tile(g);
+    int bm, bn;
+    tile_dims(tile, bm, bn);
+    const int sk = pick_splitk(D, H, B, 1, bm, bn);
+    if (sk > 1) {
+      float* slabW = W + ws.slab_b;
+      float* slabC = slabW + (int64_t)SK_MAX * D * H;
+      g.p[0].splitk = sk; g.p[0].C = slabW; g.p[0].colsum = slabC;
+      add_reduce(red, Gp + h->pol.w[L], slabW, (long)D * H, (long)D * H, sk);
+      add_reduce(red, Gp + h->pol.b[L], slabC, D, D, sk);
+    }
+    PORL_TRY(launch_group(g, tile, s));
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    const int Kin = l == 0 ? S : H;
+    const float* dz = W + ws.dz_p[l & 1];
+    const float* in = l == 0 ? W + ws.xs : W + ws.act_p[l - 1];
+    const int ldin = l == 0 ? h->Sp : Hp;
+    GemmGroup g{};
+    g.p[g.nprob] = make_prob(GEMM_TN, dz, Hp, in, ldin, Gp + h->pol.w[l], Kin, H, Kin, B);
+    g.p[g.nprob++].colsum = Gp + h->pol.b[l];
+    if (l > 0) {
+      GemmProb q = make_prob(GEMM_NN, dz, Hp, Pp + h->pol.w[l], Kin, W + ws.dz_p[(l - 1) & 1], Hp, B, Kin, H);
+      q.mask = W + ws.act_p[l - 1]; q.ldmask = Hp;
+      g.p[g.nprob++] = q;
+    }
+    const int tile = pick_tile(g);
+    if (l == 0) {
+      int bm, bn;
+      tile_dims(tile, bm, bn);
+      const int sk = pick_splitk(H, Kin, B, 1, bm, bn);
+      if (sk > 1) {
+        const int64_t per = (int64_t)H * Kin;
+        float* slabW = W + ws.slab_a;
+        float* slabC = slabW + (int64_t)SK_MAX * per;
+        g.p[0].splitk = sk; g.p[0].C = slabW; g.p[0].colsum = slabC;
+        add_reduce(red, Gp + h->pol.w[0], slabW, per, per, sk);
+        add_reduce(red, Gp + h->pol.b[0], slabC, H, H, sk);
+      }
+    }
+    PORL_TRY(launch_group(g, tile, s));
+  }
+  PORL_TRY(launch_reduce(red, s));
+  return PORL_OK;
+}
+
+int porl_iql_step(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
+  PORL_TRY(porl_iql_value_backward(h, hp, stream));
+  PORL_TRY(porl_iql_value_apply(h, hp, stream));
+  PORL_TRY(porl_iql_policy_backward(h, hp, stream));
+  PORL_TRY(porl_iql_policy_apply(h, hp, stream));
+  return PORL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+static int pack_x(porl_iql* h, const float* x, int64_t x_rs, int batch, int64_t dst_off, hipStream_t s) {
+  if (!x) PORL_FAIL(PORL_ERR_INVALID, "null input");
+  if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
+  PackArgs a{};
+  a.rows = batch; a.njobs = 1;
+  a.job[0].src = x; a.job[0].dst = h->buf.workspace + dst_off; a.job[0].src_row_stride = x_rs;
+  a.job[0].src_col_stride = 1; a.job[0].cols = h->cfg.obs_dim; a.job[0].ld = h->Sp;
+  const long n = (long)batch * h->Sp;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024), 1), dim3(256), 0, s, a);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_iql_forward_value(porl_iql* h, int which, const float* x, int64_t x_rs, int32_t batch, float* v1_out,
+                           float* v2_out, void* stream) {
+  PORL_TRY(check_ready(h, false));
+  if (!v1_out || !v2_out) PORL_FAIL(PORL_ERR_INVALID, "null output");
+  hipStream_t s = (hipStream_t)stream;
+  // uses the s' staging buffer and the target scratch activations; invalidates a loaded minibatch
+  PORL_TRY(pack_x(h, x, x_rs, batch, h->ws.xn, s));
+  h->batch = 0;
+  const int S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden;
+  float* W = h->buf.workspace;
+  const float* P = which ? h->buf.params_tgt : h->buf.params_vf;
+  int parts = 0;
+  for (int l = 0; l < L; ++l) {
+    FwdNet nets[2];
+    for (int i = 0; i < 2; ++i) {
+      FwdNet& f = nets[i];
+      if (l == 0) { f.in = W + h->ws.xn; f.ldin = h->Sp; }
+      else { f.in = W + h->ws.act_t[i][(l - 1) & 1]; f.ldin = h->Hp; }
+      f.W = P + h->v[i].w[l]; f.b = P + h->v[i].b[l];
+      f.out = l == L - 1 ? nullptr : W + h->ws.act_t[i][l & 1];
+      f.headw = P + h->v[i].w[L]; f.headout = W + h->ws.hp_t[i];
+    }
+    PORL_TRY(fwd_hidden_layer(h, nets, 2, batch, l == 0 ? S : H, l == L - 1, &parts, s));
+  }
+  hipLaunchKernelGGL(head_finish_kernel, dim3(cdiv(batch, 256)), dim3(256), 0, s, W + h->ws.hp_t[0], W + h->ws.hp_t[1],
+                     P + h->v[0].b[L], P + h->v[1].b[L], parts, batch, v1_out, v2_out);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_iql_forward_policy(porl_iql* h, const float* x, int64_t x_rs, int32_t batch, float* mean_out,
+                            int64_t mean_rs, void* stream) {
+  PORL_TRY(check_ready(h, false));
+  if (!mean_out) PORL_FAIL(PORL_ERR_INVALID, "null output");
+  hipStream_t s = (hipStream_t)stream;
+  PORL_TRY(pack_x(h, x, x_rs, batch, h->ws.xn, s));
+  h->batch = 0;
+  const int S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden, D = h->cfg.pol_out_dim;
+  float* W = h->buf.workspace;
+  const float* P = h->buf.params_pol;
+  for (int l = 0; l < L; ++l) {
+    FwdNet f{};
+    if (l == 0) { f.in = W + h->ws.xn; f.ldin = h->Sp; }
+    else { f.in = W + h->ws.act_p[l - 1]; f.ldin = h->Hp; }
+    f.W = P + h->pol.w[l]; f.b = P + h->pol.b[l]; f.out = W + h->ws.act_p[l];
+    PORL_TRY(fwd_hidden_layer(h, &f, 1, batch, l == 0 ? S : H, false, nullptr, s));
+  }
+  int nslab = 1;
+  PORL_TRY(policy_mean_slabs(h, batch, &nslab, s));
+  const long n = (long)batch * D;
+  hipLaunchKernelGGL(mean_finish_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024)), dim3(256), 0, s,
+                     W + h->ws.slab_mean, nslab, (long)batch * h->Dp, batch, D, h->Dp, P + h->pol.b[L],
+                     h->cfg.pol_tanh, mean_out, (long)mean_rs);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int porl_gemm_f32(int mode, int tile, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                  int32_t ldb, float* C, int32_t ldc, const float* bias, int act, const float* mask, int32_t ldmask,
+                  int splitk, float* slab, void* stream) {
+  if (mode < 0 || mode > 2) PORL_FAIL(PORL_ERR_INVALID, "mode must be 0..2");
+  if (M < 1 || N < 1 || K < 0 || !A || !B || !C) PORL_FAIL(PORL_ERR_INVALID, "bad GEMM arguments");
+  if (splitk > 1 && !slab) PORL_FAIL(PORL_ERR_INVALID, "splitk > 1 needs a slab buffer");
+  if (splitk > 1 && ldc != N) PORL_FAIL(PORL_ERR_INVALID, "splitk > 1 needs a dense C (ldc == N)");
+  hipStream_t s = (hipStream_t)stream;
+  GemmGroup g{};
+  g.nprob = 1;
+  g.p[0] = make_prob(mode, A, lda, B, ldb, C, ldc, M, N, K);
+  if (tile < 0) tile = pick_tile(g);
+  if (tile > 3) PORL_FAIL(PORL_ERR_INVALID, "tile must be -1..3");
+  if (splitk > 1) {
+    g.p[0].splitk = splitk; g.p[0].C = slab;
+    PORL_TRY(launch_group(g, tile, s));
+    // rows of the slab have stride ldc; combine all M*ldc floats (padding columns carry garbage that the
+    // caller's ldc padding tolerates), then apply bias/act/mask per element
+    if (mask) PORL_FAIL(PORL_ERR_UNSUPPORTED, "mask with splitk");
+    const long n = (long)M * ldc;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024)), dim3(256), 0, s, C, slab,
+                       splitk, n, n, bias, ldc, act);
+    PORL_HIP(hipGetLastError());
+    return PORL_OK;
+  }
+  g.p[0].bias = bias; g.p[0].act = act; g.p[0].mask = mask; g.p[0].ldmask = ldmask;
+  return launch_group(g, tile, s);
+}
+
+int porl_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t n, float lr, int32_t step,
+                  float beta1, float beta2, float eps, float ema_beta, void* stream) {
+  if (!p || !g || !m || !v) PORL_FAIL(PORL_ERR_INVALID, "null buffer");
+  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (target && !aligned16(target)))
+    PORL_FAIL(PORL_ERR_INVALID, "buffers must be 16-byte aligned");
+  return adam_launch(p, g, m, v, target, n, lr, step, beta1, beta2, eps, ema_beta, (hipStream_t)stream);
+}
+
+int porl_gather_rows(const float* rows, int64_t row_stride, const int64_t* idx, int32_t n, int32_t width, float* out,
+                     int64_t out_stride, void* stream) {
+  if (!rows || !idx || !out || n < 0 || width < 1) PORL_FAIL(PORL_ERR_INVALID, "bad gather arguments");
+  if (n == 0) return PORL_OK;
+  const int blocks = std::min(cdiv(n, 4), 2048);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, (long)row_stride, idx, n,
+                     width, out, (long)out_stride);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_sample_indices(int64_t n_rows, int32_t batch, uint64_t seed, uint64_t step, int64_t base, int64_t* out,
+                        void* stream) {
+  if (n_rows < 1 || batch < 1 || batch > n_rows || !out) PORL_FAIL(PORL_ERR_INVALID, "need 1 <= batch <= n_rows");
+  if (n_rows > (int64_t(1) << 40)) PORL_FAIL(PORL_ERR_INVALID, "n_rows too large");
+  int bits = 1;
+  while ((int64_t(1) << bits) < n_rows) ++bits;
+  const int hb = std::max(1, (bits + 1) / 2);
+  hipLaunchKernelGGL(sample_indices_kernel, dim3(cdiv(batch, 256)), dim3(256), 0, (hipStream_t)stream, n_rows, batch,
+                     seed, step, hb, base, out);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_prof_enable(int on) {
+  g_prof.on = on != 0;
+  g_prof.recs.clear();
+  g_prof.pool_used = 0;
+  return PORL_OK;
+}
+
+int porl_prof_read(porl_prof_entry* out, int max_entries) {
+  if (!out || max_entries < 1) PORL_FAIL(PORL_ERR_INVALID, "bad profile buffer");
+  PORL_HIP(hipDeviceSynchronize());
+  const int nl = std::min<int>((int)g_prof.labels.size(), max_entries);
+  for (int i = 0; i < nl; ++i) {
+    memset(&out[i], 0, sizeof(out[i]));
+    strncpy(out[i].name, g_prof.labels[i].c_str(), sizeof(out[i].name) - 1);
+  }
+  for (const ProfRec& r : g_prof.recs) {
+    if (r.label >= nl) continue;
+    float ms = 0.f;
+    PORL_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+    out[r.label].launches += 1;
+    out[r.label].total_ms += ms;
+    out[r.label].flops += r.flops;
+    out[r.label].bytes += r.bytes;
+  }
+  return nl;
+}
+
+}  // extern "C"

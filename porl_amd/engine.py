@@ -1,0 +1,217 @@
+"""Host-side owner of one IQL-family update engine (POR / SORL) on one MI355X.
+
+PyTorch supplies device memory and the stream; all arithmetic of the step runs in libporl_hip.so
+(porl_amd/_native.py).  Parameters, gradients and Adam moments each live in ONE flat fp32 tensor per
+optimizer group so the Adam(+EMA) sweep and the data-parallel all-reduce are single operations; the
+nn.Parameters of the agent modules are views into those tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _native as N
+
+
+class IqlEngine:
+    GROUP_VF, GROUP_POL = 0, 1
+
+    def __init__(self, obs_dim, pol_out_dim, hidden_dim, n_hidden, layer_norm=False, pol_tanh=False,
+                 weight_mode=0, max_batch=1024, device="cpu"):
+        self.device = torch.device(device)
+        self.cfg = N.IqlCfg(int(obs_dim), int(pol_out_dim), int(hidden_dim), int(n_hidden),
+                            int(bool(layer_norm)), int(bool(pol_tanh)), int(weight_mode), int(max_batch))
+        self._lib = N.lib()
+        h = C.c_void_p()
+        N.check(self._lib.porl_iql_create(C.byref(self.cfg), C.byref(h)), "porl_iql_create")
+        self._h = h
+        self.n_vf = int(self._lib.porl_iql_group_floats(h, 0))
+        self.n_pol = int(self._lib.porl_iql_group_floats(h, 1))
+        self._bound = False
+        self._alloc()
+
+    # -- memory ------------------------------------------------------------------------------------
+    def _alloc(self):
+        dev = self.device
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+        self.params_vf, self.params_tgt, self.params_pol = z(self.n_vf), z(self.n_vf), z(self.n_pol)
+        self.grads_vf, self.grads_pol = z(self.n_vf), z(self.n_pol)
+        self.adam_m_vf, self.adam_v_vf = z(self.n_vf), z(self.n_vf)
+        self.adam_m_pol, self.adam_v_pol = z(self.n_pol), z(self.n_pol)
+        self.stats = z(8)
+        self.workspace = None
+        self._bound = False
+
+    def _ensure_bound(self):
+        if self.device.type != "cuda":
+            raise N.NativeError("porl_amd computes on a HIP device only (device='cuda'); there is no CPU path")
+        if self._bound:
+            return
+        nws = int(self._lib.porl_iql_workspace_floats(self._h))
+        self.workspace = torch.empty(nws, dtype=torch.float32, device=self.device)
+        b = N.IqlBuffers(*[C.c_void_p(t.data_ptr()) for t in (
+            self.params_vf, self.params_tgt, self.params_pol, self.grads_vf, self.grads_pol,
+            self.adam_m_vf, self.adam_v_vf, self.adam_m_pol, self.adam_v_pol, self.workspace, self.stats)])
+        N.check(self._lib.porl_iql_bind(self._h, C.byref(b)), "porl_iql_bind")
+        self._bound = True
+
+    def to(self, device):
+        """Move every flat tensor; views handed out earlier must be re-created by the caller."""
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        for name in ("params_vf", "params_tgt", "params_pol", "grads_vf", "grads_pol", "adam_m_vf",
+                     "adam_v_vf", "adam_m_pol", "adam_v_pol", "stats"):
+            setattr(self, name, getattr(self, name).to(device))
+        self.device = device
+        self.workspace = None
+        self._bound = False
+        return self
+
+    def tensor_table(self, group):
+        """[(offset, shape)] of a group's tensors in named_parameters() order."""
+        n = int(self._lib.porl_iql_group_tensors(self._h, group))
+        out = []
+        off, r, c = C.c_int64(), C.c_int32(), C.c_int32()
+        for i in range(n):
+            N.check(self._lib.porl_iql_tensor_info(self._h, group, i, C.byref(off), C.byref(r), C.byref(c)))
+            out.append((off.value, (c.value,) if r.value == 0 else (r.value, c.value)))
+        return out
+
+    @staticmethod
+    def views(flat, table):
+        return [flat[o:o + math.prod(shape)].view(shape) for o, shape in table]
+
+    # -- step --------------------------------------------------------------------------------------
+    @staticmethod
+    def _mat(t, cols, what):
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{what}: expected float32, got {t.dtype}")
+        if t.dim() != 2 or t.shape[1] != cols:
+            raise RuntimeError(f"{what}: expected shape (B, {cols}), got {tuple(t.shape)}")
+        if t.stride(1) != 1:
+            t = t.contiguous()
+        return t
+
+    def _vec(self, t, B, what):
+        if t.dim() != 1 or t.shape[0] != B:
+            raise RuntimeError(f"{what}: expected shape ({B},), got {tuple(t.shape)}")
+        return t if t.dtype == torch.float32 else t.float()
+
+    def load_batch(self, obs, next_obs, rew, term, pol_target=None):
+        self._ensure_bound()
+        for t in (obs, next_obs, rew, term, pol_target):
+            if t is not None and t.device != self.device:
+                raise RuntimeError(f"batch tensor on {t.device}, engine on {self.device}")
+        S, D = self.cfg.obs_dim, self.cfg.pol_out_dim
+        obs, next_obs = self._mat(obs, S, "observations"), self._mat(next_obs, S, "next_observations")
+        B = obs.shape[0]
+        if next_obs.shape[0] != B:
+            raise RuntimeError("observations / next_observations batch mismatch")
+        if B > self.cfg.max_batch:
+            raise RuntimeError(f"batch {B} exceeds engine max_batch {self.cfg.max_batch}")
+        rew, term = self._vec(rew, B, "rewards"), self._vec(term, B, "terminals")
+        if pol_target is not None:
+            pol_target = self._mat(pol_target, D, "policy target")
+        # keep references alive until the pack kernel has run (stream-ordered; torch caches the memory)
+        self._held = (obs, next_obs, rew, term, pol_target)
+        N.check(self._lib.porl_iql_load_batch(
+            self._h, B, N.ptr(obs), obs.stride(0), N.ptr(next_obs), next_obs.stride(0),
+            N.ptr(rew), rew.stride(0), N.ptr(term), term.stride(0),
+            N.ptr(pol_target), 0 if pol_target is None else pol_target.stride(0),
+            N.current_stream_ptr()), "porl_iql_load_batch")
+        return B
+
+    def hyper(self, **kw):
+        d = dict(tau=0.9, discount=0.99, alpha=10.0, ema_beta=0.005, inv_batch=1.0, value_lr=1e-4,
+                 policy_lr=1e-4, value_step=1, policy_step=1, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)
+        d.update(kw)
+        return N.IqlHyper(**d)
+
+    def _phase(self, name, hp):
+        N.check(getattr(self._lib, name)(self._h, C.byref(hp), N.current_stream_ptr()), name)
+
+    def value_backward(self, hp): self._phase("porl_iql_value_backward", hp)
+    def value_apply(self, hp): self._phase("porl_iql_value_apply", hp)
+    def policy_backward(self, hp): self._phase("porl_iql_policy_backward", hp)
+    def policy_apply(self, hp): self._phase("porl_iql_policy_apply", hp)
+    def step(self, hp): self._phase("porl_iql_step", hp)
+
+    # -- forward-only ------------------------------------------------------------------------------
+    def forward_value(self, x, target=False):
+        self._ensure_bound()
+        x = self._mat(x, self.cfg.obs_dim, "state")
+        B = x.shape[0]
+        v1 = torch.empty(B, dtype=torch.float32, device=self.device)
+        v2 = torch.empty_like(v1)
+        N.check(self._lib.porl_iql_forward_value(self._h, int(target), N.ptr(x), x.stride(0), B, N.ptr(v1),
+                                                 N.ptr(v2), N.current_stream_ptr()), "porl_iql_forward_value")
+        return v1, v2
+
+    def forward_policy(self, x):
+        self._ensure_bound()
+        x = self._mat(x, self.cfg.obs_dim, "obs")
+        B, D = x.shape[0], self.cfg.pol_out_dim
+        mean = torch.empty(B, D, dtype=torch.float32, device=self.device)
+        N.check(self._lib.porl_iql_forward_policy(self._h, N.ptr(x), x.stride(0), B, N.ptr(mean), D,
+                                                  N.current_stream_ptr()), "porl_iql_forward_policy")
+        return mean
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.porl_iql_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+# -- thin wrappers over the building blocks ---------------------------------------------------------
+def gemm_f32(mode, A, B, M, N_, K, lda, ldb, C_out, ldc, bias=None, act=0, mask=None, ldmask=0, tile=-1,
+             splitk=1, slab=None):
+    """Test/utility entry: raw pointers of torch tensors, see include/porl_hip.h:porl_gemm_f32."""
+    N.check(N.lib().porl_gemm_f32(mode, tile, M, N_, K, N.ptr(A), lda, N.ptr(B), ldb, N.ptr(C_out), ldc,
+                                  N.ptr(bias), act, N.ptr(mask), ldmask, splitk, N.ptr(slab),
+                                  N.current_stream_ptr()), "porl_gemm_f32")
+
+
+def adam_ema(p, g, m, v, target, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, ema_beta=0.0):
+    N.check(N.lib().porl_adam_ema(N.ptr(p), N.ptr(g), N.ptr(m), N.ptr(v), N.ptr(target), p.numel(), lr, step,
+                                  beta1, beta2, eps, ema_beta, N.current_stream_ptr()), "porl_adam_ema")
+
+
+def gather_rows(rows, idx, out=None):
+    """out[i] = rows[idx[i]] for a 2-D fp32 (or bit-reinterpreted) device tensor."""
+    if rows.dim() != 2 or rows.stride(1) != 1:
+        raise RuntimeError("rows must be 2-D with unit column stride")
+    n, w = idx.numel(), rows.shape[1]
+    if out is None:
+        out = torch.empty(n, w, dtype=rows.dtype, device=rows.device)
+    N.check(N.lib().porl_gather_rows(N.ptr(rows), rows.stride(0), N.ptr(idx), n, w, N.ptr(out), out.stride(0),
+                                     N.current_stream_ptr()), "porl_gather_rows")
+    return out
+
+
+def sample_indices(n_rows, batch, seed, step, out=None, base=0, device="cuda"):
+    """`batch` distinct row indices in [base, base + n_rows) drawn on the device (int64)."""
+    if out is None:
+        out = torch.empty(batch, dtype=torch.int64, device=device)
+    N.check(N.lib().porl_sample_indices(n_rows, batch, seed, step, base, N.ptr(out), N.current_stream_ptr()),
+            "porl_sample_indices")
+    return out
+
+
+def prof_enable(on=True):
+    N.check(N.lib().porl_prof_enable(int(on)), "porl_prof_enable")
+
+
+def prof_read(max_entries=64):
+    """[{name, launches, total_ms, flops, bytes}] — synchronises the device."""
+    buf = (N.ProfEntry * max_entries)()
+    n = N.lib().porl_prof_read(buf, max_entries)
+    if n < 0:
+        N.check(n, "porl_prof_read")
+    return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), total_ms=float(buf[i].total_ms),
+                 flops=float(buf[i].flops), bytes=float(buf[i].bytes)) for i in range(n)]

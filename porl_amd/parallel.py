@@ -1,0 +1,52 @@
+"""Data-parallel exchange for the sharded-replay configuration (BASELINE config 4).
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in CPU
+tests).  The replay buffer is row-sharded, every rank draws B_local rows of its own shard and scales
+its loss gradients by 1/(world * B_local), so a SUM all-reduce of the flat gradient group yields the
+gradient of the global-batch mean (SURVEY.md §5.8 parity rule).  The reference has no distributed
+code; this is a new capability.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+class GradExchange:
+    def __init__(self, group=None):
+        self.group = group
+
+    @property
+    def world_size(self):
+        d = _dist()
+        return d.get_world_size(self.group) if d else 1
+
+    @property
+    def rank(self):
+        d = _dist()
+        return d.get_rank(self.group) if d else 0
+
+    def allreduce_sum_(self, flat: torch.Tensor):
+        d = _dist()
+        if d and d.get_world_size(self.group) > 1:
+            d.all_reduce(flat, op=d.ReduceOp.SUM, group=self.group)
+        return flat
+
+    def allreduce_stats_(self, stats: torch.Tensor):
+        """stats[0:2] = (v_loss, g_loss) shares -> SUM; stats[2] = min NLL -> MIN."""
+        d = _dist()
+        if d and d.get_world_size(self.group) > 1:
+            d.all_reduce(stats[0:2], op=d.ReduceOp.SUM, group=self.group)
+            d.all_reduce(stats[2:3], op=d.ReduceOp.MIN, group=self.group)
+        return stats
+
+
+def shard_bounds(n_rows: int, rank: int, world: int):
+    """Rows [lo, hi) of the replay store owned by `rank` (contiguous, sizes differ by at most 1)."""
+    base, rem = divmod(n_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

@@ -1,0 +1,201 @@
+"""End-to-end parity of the HIP update step (through the agent classes and the C ABI) against the
+numpy oracle and the reference-generated golden vectors.  GPU only.
+
+Tolerances (fp32, BASELINE.json north_star "within 1e-5"): losses rtol 1e-5 (g_loss ~ 80, 1 ulp =
+7.6e-6 absolute); parameters max-abs 1e-5 after K steps.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from oracle.por_oracle import PorOracle, sorl_oracle
+from porl_amd.util.synth import make_rows, split_rows
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+LOSS_RTOL, PARAM_ATOL = 1e-5, 1e-5
+
+
+def _args(S, H, L, ln=False, A=2, B=1024):
+    return SimpleNamespace(state_size=S, hidden_dim=H, n_hidden=L, layer_norm=ln, feature_dim=256,
+                           action_size=A, max_batch=B)
+
+
+def _np_sd(agent):
+    return {k: v.detach().cpu().numpy() for k, v in agent.state_dict().items()}
+
+
+def _cmp_params(got, ref, atol=PARAM_ATOL):
+    worst = ("", 0.0)
+    for k in ref:
+        err = float(np.abs(got[k].astype(np.float64) - ref[k]).max())
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] <= atol, f"max-abs param error {worst[1]:.3e} at {worst[0]}"
+
+
+def _make_por(S, H, L, B, seed=0, **kw):
+    from porl_amd.agent.por import POR
+    torch.manual_seed(seed)
+    return POR(_args(S, H, L, B=B), kw.pop("max_steps", 1000), kw.pop("tau", 0.9), kw.pop("alpha", 10.0),
+               device=DEV, **kw)
+
+
+@pytest.mark.parametrize("name", ["por_s60_h64_b32", "por_s17_h48_l3_b50"])
+def test_por_matches_reference_golden(name):
+    z, meta = load_golden(name)
+    S, H, L, B, K, A = (int(meta[k]) for k in ("S", "H", "L", "B", "K", "A"))
+    agent = _make_por(S, H, L, B, seed=int(meta["seed_model"]), tau=meta["tau"], alpha=meta["alpha"])
+    init = sub(z, "init/")
+    _cmp_params(_np_sd(agent), init, atol=0.0)         # same seed -> the reference's initial weights
+    rows = torch.from_numpy(make_rows(K * B, S, A, seed=int(meta["seed_data"]))).to(DEV)
+    for k in range(K):
+        batch = rows[k * B:(k + 1) * B]                # strided column views, like por_train.py:74-78
+        s, r, sp, d, a = split_rows(batch, S, A)
+        vl, gl = agent.por_residual_update(s, sp, r, d)
+        np.testing.assert_allclose(vl, z["v_loss"][k], rtol=LOSS_RTOL)
+        np.testing.assert_allclose(gl, z["g_loss"][k], rtol=LOSS_RTOL)
+        np.testing.assert_allclose(agent.goal_lr_schedule.get_last_lr()[0], z["goal_lr_after"][k], rtol=1e-12)
+    _cmp_params(_np_sd(agent), sub(z, "final/"))
+    # optimizer state interchange (torch.optim.Adam format)
+    am = sub(z, "adam_v/")
+    sd = agent.v_optimizer.state_dict()
+    names = [n for n, _ in agent.vf.named_parameters(prefix="vf")]
+    for i, n in enumerate(names):
+        np.testing.assert_allclose(sd["state"][i]["exp_avg"].cpu().numpy(), am[n + ".exp_avg"], atol=1e-7, rtol=1e-4)
+        assert float(sd["state"][i]["step"]) == float(am["__step__"])
+
+
+def _phase_check(agent, oracle, s, sp, r, d, tag):
+    """Run one update phase by phase on the engine and compare gradients with the oracle."""
+    eng = agent._engine
+    o = oracle
+    s_np, sp_np, r_np, d_np = (t.cpu().numpy() for t in (s, sp, r, d))
+    B = eng.load_batch(s, sp, r, d, sp)
+    agent.v_optimizer.step_count += 1
+    agent.goal_policy_optimizer.step_count += 1
+    hp = agent._hyper(B, agent.v_optimizer, agent.goal_policy_optimizer)
+    eng.value_backward(hp)
+    v_loss_o, target_o = o.value_update(np.ascontiguousarray(s_np), np.ascontiguousarray(sp_np), r_np, d_np)
+    from porl_amd.engine import IqlEngine
+    gv = IqlEngine.views(eng.grads_vf, eng.tensor_table(0))
+    for (n, _), g in zip(agent.vf.named_parameters(prefix="vf"), gv):
+        ref = o.last_vf_grads[n]
+        scale = max(1e-30, float(np.abs(ref).max()))
+        err = float(np.abs(g.cpu().numpy() - ref).max()) / scale
+        assert err < 2e-5, f"{tag}: grad {n} rel-to-max error {err:.2e}"
+    np.testing.assert_allclose(float(eng.stats[0]), v_loss_o, rtol=LOSS_RTOL)
+    eng.value_apply(hp)
+    eng.policy_backward(hp)
+    g_loss_o = o.policy_update(np.ascontiguousarray(s_np), target_o, np.ascontiguousarray(sp_np))
+    gp = IqlEngine.views(eng.grads_pol, eng.tensor_table(1))
+    for (n, _), g in zip(agent.goal_policy.named_parameters(prefix="goal_policy"), gp):
+        ref = o.last_pol_grads[n]
+        scale = max(1e-30, float(np.abs(ref).max()))
+        err = float(np.abs(g.cpu().numpy() - ref).max()) / scale
+        assert err < 2e-5, f"{tag}: grad {n} rel-to-max error {err:.2e}"
+    np.testing.assert_allclose(float(eng.stats[1]), g_loss_o, rtol=LOSS_RTOL)
+    np.testing.assert_allclose(float(eng.stats[2]), o.last_min_nlp, rtol=LOSS_RTOL)
+    eng.policy_apply(hp)
+    agent.goal_lr_schedule.step()
+
+
+@pytest.mark.parametrize("S,H,L,B", [(60, 64, 2, 32), (60, 256, 2, 256), (17, 48, 3, 50), (60, 128, 1, 100),
+                                     (362, 64, 2, 16), (60, 1024, 2, 1024)])
+def test_por_phases_vs_oracle(S, H, L, B):
+    agent = _make_por(S, H, L, B)
+    o = PorOracle(_np_sd(agent), S, H, L)
+    rows = torch.from_numpy(make_rows(3 * B, S, 2, seed=7)).to(DEV)
+    for k in range(3):
+        s, r, sp, d, a = split_rows(rows[k * B:(k + 1) * B], S, 2)
+        _phase_check(agent, o, s, sp, r, d, f"step{k}")
+    _cmp_params(_np_sd(agent), o.P)
+
+
+@pytest.mark.parametrize("name", ["por_s60_h256_b256", "por_s60_h1024_b256", "por_s60_h1024_b1024"])
+def test_por_baseline_configs_vs_golden_losses(name):
+    """BASELINE configs 1/2 (H=1024, B=256/1024): losses against the reference's recorded values and
+    all 5.6 M parameters against the oracle (itself pinned to the reference's checksums)."""
+    z, meta = load_golden(name)
+    S, H, L, B, K, A = (int(meta[k]) for k in ("S", "H", "L", "B", "K", "A"))
+    agent = _make_por(S, H, L, B, seed=int(meta["seed_model"]))
+    o = PorOracle(_np_sd(agent), S, H, L)
+    rows_np = make_rows(K * B, S, A, seed=int(meta["seed_data"]))
+    rows = torch.from_numpy(rows_np).to(DEV)
+    for k in range(K):
+        s, r, sp, d, a = split_rows(rows[k * B:(k + 1) * B], S, A)
+        vl, gl = agent.por_residual_update(s, sp, r, d)
+        np.testing.assert_allclose(vl, z["v_loss"][k], rtol=LOSS_RTOL)
+        np.testing.assert_allclose(gl, z["g_loss"][k], rtol=LOSS_RTOL)
+        sn, rn, spn, dn, _ = split_rows(rows_np[k * B:(k + 1) * B], S, A)
+        o.por_residual_update(sn, spn, rn, dn)
+    _cmp_params(_np_sd(agent), o.P)
+
+
+def test_por_forward_api_and_state_dict_roundtrip():
+    agent = _make_por(60, 64, 2, 64)
+    o = PorOracle(_np_sd(agent), 60, 64, 2)
+    x = torch.from_numpy(make_rows(40, 60, 2, seed=3)[:, :60].copy()).to(DEV)
+    v1, v2 = agent.vf.both(x)
+    from oracle.por_oracle import twin_forward, mlp_forward
+    r1, r2, _, _ = twin_forward(o.P, "vf", x.cpu().numpy(), 2, False)
+    np.testing.assert_allclose(v1.cpu().numpy(), r1, atol=2e-6)
+    np.testing.assert_allclose(agent.vf(x).cpu().numpy(), np.minimum(r1, r2), atol=2e-6)
+    t1, _ = agent.v_target.both(x)
+    np.testing.assert_allclose(t1.cpu().numpy(), r1, atol=2e-6)      # target == vf at init
+    dist = agent.goal_policy(x)
+    mean_ref, _ = mlp_forward(o.P, "goal_policy.net", x.cpu().numpy(), 2)
+    np.testing.assert_allclose(dist.mean.cpu().numpy(), mean_ref, atol=2e-6)
+    # state_dict -> fresh agent -> identical update
+    sd = {k: v.clone() for k, v in agent.state_dict().items()}
+    other = _make_por(60, 64, 2, 64, seed=123)
+    other.load_state_dict(sd)
+    rows = torch.from_numpy(make_rows(64, 60, 2, seed=9)).to(DEV)
+    s, r, sp, d, a = split_rows(rows, 60, 2)
+    assert agent.por_residual_update(s, sp, r, d) == other.por_residual_update(s, sp, r, d)
+
+
+@pytest.mark.parametrize("name", ["sorl_s60_h64_b32", "sorl_s362_h64_b16_a10"])
+def test_sorl_matches_reference_golden(name):
+    from porl_amd.agent.sorl import SORL
+    z, meta = load_golden(name)
+    S, H, L, B, K, A = (int(meta[k]) for k in ("S", "H", "L", "B", "K", "A"))
+    torch.manual_seed(int(meta["seed_model"]))
+    agent = SORL(_args(S, H, L, A=A, B=B), int(meta["max_steps"]), meta["tau"], meta["alpha"], device=DEV)
+    _cmp_params(_np_sd(agent), sub(z, "init/"), atol=0.0)
+    rows = torch.from_numpy(make_rows(K * B, S, A, seed=int(meta["seed_data"]))).to(DEV)
+    for k in range(K):
+        s, r, sp, d, a = split_rows(rows[k * B:(k + 1) * B], S, A)
+        vl, gl = agent.update(s, a, r, sp, d)
+        np.testing.assert_allclose(vl, z["v_loss"][k], rtol=LOSS_RTOL)
+        np.testing.assert_allclose(gl, z["g_loss"][k], rtol=2e-5)
+    _cmp_params(_np_sd(agent), sub(z, "final/"))
+    np.testing.assert_allclose(agent.select_action(rows[:8, :S]), z["select_action"], atol=2e-6)
+
+
+def test_sorl_vf_update_matches_reference_golden():
+    from porl_amd.agent.sorl import SORL
+    z, meta = load_golden("sorl_vf_s60_h64_b32")
+    S, H, L, B, K, A = (int(meta[k]) for k in ("S", "H", "L", "B", "K", "A"))
+    torch.manual_seed(int(meta["seed_model"]))
+    agent = SORL(_args(S, H, L, A=A, B=B), 1000, meta["tau"], meta["alpha"], device=DEV)
+    rows = torch.from_numpy(make_rows(K * B, S, A, seed=int(meta["seed_data"]))).to(DEV)
+    for k in range(K):
+        s, r, sp, d, a = split_rows(rows[k * B:(k + 1) * B], S, A)
+        np.testing.assert_allclose(agent.vf_update(s, a, r, sp, d), z["v_loss"][k], rtol=LOSS_RTOL)
+    _cmp_params(_np_sd(agent), sub(z, "final/"))
+
+
+def test_error_conventions():
+    agent = _make_por(60, 64, 2, 32)
+    rows = torch.from_numpy(make_rows(64, 60, 2, seed=1)).to(DEV)
+    s, r, sp, d, a = split_rows(rows, 60, 2)
+    with pytest.raises(RuntimeError):                       # batch larger than the engine was sized for
+        agent.por_residual_update(s, sp, r, d)
+    with pytest.raises(RuntimeError):                       # wrong feature width
+        agent.por_residual_update(s[:32, :59], sp[:32], r[:32], d[:32])
+    with pytest.raises(RuntimeError):                       # wrong device
+        agent.por_residual_update(s[:32].cpu(), sp[:32], r[:32], d[:32])
