@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: POR gradient-steps/sec (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full POR update (agent/por.py:73-112 of the reference) INCLUDING minibatch
+acquisition: draw B distinct rows of the device-resident replay shard, gather them, run value step +
+EMA + policy step.  Workload at N=1 is BASELINE config 2 (S=60, A=2, H=1024, L=2, B=1024, 1 M-row
+buffer, fp32); at N>1 every rank keeps its own 1.25 M-row shard (N=8 -> the 10 M-row buffer of config 4)
+and draws B=1024 local rows — weak scaling, gradients all-reduced with RCCL.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : dominant kernel (the 128x128 fp32-MFMA grouped GEMM) timed with HIP events on its
+                 launch stream in a second, instrumented pass over the same K steps
+  cpu_baseline : the numpy oracle (oracle/por_oracle.py, BLAS threads stated) timed on the host cores
+                 on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+S, A, H, L, B = 60, 2, 1024, 2, 1024
+
+
+def por_flops_per_sample():
+    """14 440 448 MAC per sample."""
+    mac_v = S * H + H * H + H
+    mac_p = S * H + H * H + H * S
+    fwd = 6 * mac_v + mac_p
+    bwd = 2 * (mac_v + H * H + H) + (mac_p + H * H + H * S)
+    return 2 * (fwd + bwd)
+
+
+def cpu_baseline(budget_s=15.0):
+    """Numpy-oracle steps/s on the host, same shapes, bounded by wall time."""
+    import numpy as np
+    from oracle.por_oracle import PorOracle
+    from porl_amd.util.init import build_por_state_dict
+    from porl_amd.util.synth import make_rows, split_rows
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    o = PorOracle(build_por_state_dict(S, H, L, seed=0), S, H, L)
+    rows = make_rows(8 * B, S, A, seed=0)
+    s, r, sp, d, _ = split_rows(rows[:B], S, A)
+    o.por_residual_update(s, sp, r, d)                       # warm-up (BLAS threads, page faults)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        k = (n + 1) % 8
+        s, r, sp, d, _ = split_rows(rows[k * B:(k + 1) * B], S, A)
+        o.por_residual_update(s, sp, r, d)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s and n >= 3:
+            break
+    return dict(value=n / el, unit="gradient-steps/sec", cores=int(cores), kind="port",
+                sample=f"{n} POR updates (B={B}, H={H}, S={S}) of oracle/por_oracle.py (numpy fp32, BLAS) in {el:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows-per-gpu", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from types import SimpleNamespace
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from porl_amd.agent.por import POR
+    from porl_amd.buffer.replay_buffer import PackedReplay
+    from porl_amd.util.synth import make_rows
+    from porl_amd import engine as E
+
+    rows_per_gpu = a.rows_per_gpu or (1_000_000 if world == 1 else 1_250_000)
+    # every rank generates only its own shard (same generator family, rank-keyed seed)
+    shard = make_rows(rows_per_gpu, S, A, seed=1000 + rank)
+    replay = PackedReplay(shard, S, A, dev, rank=0, world=1, seed=rank)
+    del shard
+
+    args = SimpleNamespace(state_size=S, hidden_dim=H, n_hidden=L, layer_norm=False, action_size=A, max_batch=B)
+    torch.manual_seed(0)                                       # identical replicas on every rank
+    agent = POR(args, max_steps=1000, tau=0.9, alpha=10.0, device=dev)
+    agent.async_losses = True                                  # no host sync inside the loop
+    losses = torch.zeros(a.steps + a.warmup, 3, device=dev)
+
+    def one_step(i):
+        batch = replay.sample(B)
+        s, r, sp, d, _ = replay.split(batch)
+        losses[i] = agent.por_residual_update(s, sp, r, d)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        one_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        one_step(a.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    lh = losses.cpu().numpy()
+    if not np.isfinite(lh).all():
+        raise SystemExit("non-finite loss in the benchmark run")
+
+    roof = None
+    if not a.no_roofline:
+        # second pass, instrumented: HIP events around every kernel launch on the launch stream
+        E.prof_enable(True)
+        for i in range(a.steps):
+            one_step(a.warmup + i)
+        prof = E.prof_read()
+        E.prof_enable(False)
+        gemms = [p for p in prof if p["name"].startswith("gemm_f32_kernel") and p["launches"]]
+        if gemms:
+            dom = max(gemms, key=lambda p: p["total_ms"])
+            avg_ms = dom["total_ms"] / dom["launches"]
+            flops_per_launch = dom["flops"] / dom["launches"]
+            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel=dom["name"], achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=None,
+                        avg_launch_us=avg_ms * 1e3, launches=dom["launches"],
+                        flop_per_launch=flops_per_launch,
+                        all_kernels_ms_per_step={p["name"]: p["total_ms"] / a.steps for p in prof if p["launches"]})
+
+    if rank == 0:
+        steps_per_s = a.steps / elapsed
+        out = {
+            "metric": "gradient-steps/sec (POR update, batch=1024 per GPU)",
+            "value": steps_per_s, "unit": "gradient-steps/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"POR S={S} A={A} H={H} L={L} B={B}/GPU (global {B * world}), "
+                                   f"{rows_per_gpu * world} -row replay ({rows_per_gpu}/GPU) resident in HBM, "
+                                   "device sampler + gather + full update per step",
+                       "parallelism": f"dp{world}", "global_batch": B * world},
+            "samples_per_sec": steps_per_s * B * world,
+            "algorithmic_tflops": steps_per_s * B * world * por_flops_per_sample() / 1e12,
+            "final_losses": {"v_loss": float(lh[-1, 0]), "g_loss": float(lh[-1, 1])},
+        }
+        if roof:
+            out["roofline"] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["speedup_vs_cpu_baseline"] = steps_per_s / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

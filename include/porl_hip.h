@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define PORL_ABI_VERSION 1
+#define PORL_ABI_VERSION 2
 #define PORL_MAX_HIDDEN 8
 
 #define PORL_OK 0
@@ -99,13 +99,16 @@ typedef struct porl_iql_hyper {
   float tau;         /* expectile                                   */
   float discount;    /* gamma                                       */
   float alpha;       /* advantage temperature                       */
-  float ema_beta;    /* Polyak coefficient (por.py:31, beta=0.005)  */
   float inv_batch;   /* 1/B_global: a data-parallel shard passes 1/(world*B_local) */
-  float value_lr;    /* constant (no schedule on the value optimizer) */
-  float policy_lr;   /* CosineAnnealingLR value for THIS update (host-computed, Appendix A.3) */
   int32_t value_step;   /* Adam step counter t >= 1 of the value optimizer for this update  */
   int32_t policy_step;  /* ditto for the policy optimizer                                   */
-  float adam_beta1, adam_beta2, adam_eps;   /* torch defaults 0.9, 0.999, 1e-8 */
+  int32_t reserved;
+  /* torch keeps these as Python doubles and rounds derived quantities (1-beta, lr/bias_correction) to
+   * fp32 once; they are doubles here so that the same roundings happen */
+  double ema_beta;   /* Polyak coefficient (por.py:31, beta=0.005)  */
+  double value_lr;   /* constant (no schedule on the value optimizer) */
+  double policy_lr;  /* CosineAnnealingLR value for THIS update (host-computed, Appendix A.3) */
+  double adam_beta1, adam_beta2, adam_eps;   /* torch defaults 0.9, 0.999, 1e-8 */
 } porl_iql_hyper;
 
 /* por.py:81-89 — target-V forward, TD target, twin forward, expectile loss, backward.
@@ -144,7 +147,7 @@ int porl_gemm_f32(int mode, int tile, int32_t M, int32_t N, int32_t K,
 /* torch.optim.Adam single-tensor arithmetic over a flat range (n multiple of 4, 16-byte aligned),
  * optionally fused with target <- (1-ema_beta) target + ema_beta p (target may be NULL). */
 int porl_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t n,
-                  float lr, int32_t step, float beta1, float beta2, float eps, float ema_beta,
+                  double lr, int32_t step, double beta1, double beta2, double eps, double ema_beta,
                   void* stream);
 
 /* out[i,:] = rows[idx[i],:] — minibatch gather from a device-resident packed-row replay store

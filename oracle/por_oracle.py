@@ -21,10 +21,20 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-F32 = np.float32
+F32 = np.float32       # working precision; set_precision(np.float64) gives the exact-arithmetic "truth"
 LOG_STD_MIN, LOG_STD_MAX = -5.0, 2.0      # /root/reference/agent/policy.py:8-9
 EXP_ADV_MAX = 100.0                        # /root/reference/agent/por.py:12
 LN_EPS = 1e-5                              # torch.nn.LayerNorm default (util/util.py:36-37)
+
+
+def set_precision(dtype):
+    """Switch the oracle's working precision (np.float32 default).  With np.float64 the same formulas
+    give the exact-arithmetic result up to 1e-16, which tests use as the common yardstick: two fp32
+    implementations (MKL, BLAS, MFMA) agree with it to rounding, but can disagree with EACH OTHER by
+    ~1e-5 on a handful of weights whenever a ReLU pre-activation or an Adam denominator sits within
+    rounding distance of its kink ("what 1e-5 parity means")."""
+    global F32
+    F32 = dtype
 
 
 # ---------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libporl_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/porl_hip.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
@@ -38,10 +38,10 @@ class IqlBuffers(C.Structure):
 
 
 class IqlHyper(C.Structure):
-    _fields_ = [("tau", C.c_float), ("discount", C.c_float), ("alpha", C.c_float),
-                ("ema_beta", C.c_float), ("inv_batch", C.c_float), ("value_lr", C.c_float),
-                ("policy_lr", C.c_float), ("value_step", C.c_int32), ("policy_step", C.c_int32),
-                ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float)]
+    _fields_ = [("tau", C.c_float), ("discount", C.c_float), ("alpha", C.c_float), ("inv_batch", C.c_float),
+                ("value_step", C.c_int32), ("policy_step", C.c_int32), ("reserved", C.c_int32),
+                ("ema_beta", C.c_double), ("value_lr", C.c_double), ("policy_lr", C.c_double),
+                ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
 
 
 class ProfEntry(C.Structure):
@@ -57,7 +57,7 @@ _lib = None
 
 
 def _declare(lib):
-    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
     lib.porl_abi_version.restype = C.c_int
     lib.porl_last_error.restype = C.c_char_p
     lib.porl_iql_create.argtypes = [C.POINTER(IqlCfg), C.POINTER(vp)]
@@ -79,7 +79,7 @@ def _declare(lib):
     lib.porl_iql_forward_policy.argtypes = [vp, vp, i64, i32, vp, i64, vp]
     lib.porl_gemm_f32.argtypes = [C.c_int, C.c_int, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, C.c_int,
                                   vp, i32, C.c_int, vp, vp]
-    lib.porl_adam_ema.argtypes = [vp, vp, vp, vp, vp, i64, f32, i32, f32, f32, f32, f32, vp]
+    lib.porl_adam_ema.argtypes = [vp, vp, vp, vp, vp, i64, f64, i32, f64, f64, f64, f64, vp]
     lib.porl_gather_rows.argtypes = [vp, i64, vp, i32, i32, vp, i64, vp]
     lib.porl_sample_indices.argtypes = [i64, i32, C.c_uint64, C.c_uint64, i64, vp, vp]
     lib.porl_prof_enable.argtypes = [C.c_int]

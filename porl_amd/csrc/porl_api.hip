@@ -52,7 +52,7 @@ struct ProfState {
   std::vector<hipEvent_t> pool;
   size_t pool_used = 0;
   hipEvent_t get() {
-    if (pool_used == pool.size()) { hipEvent_t e; hipEventCreate(&e); pool.push_back(e); }
+    if (pool_used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
     return pool[pool_used++];
   }
   int label_id(const std::string& s) {
@@ -68,11 +68,11 @@ struct ProfScope {
     if (!active) return;
     r.label = g_prof.label_id(label); r.flops = flops; r.bytes = bytes;
     r.e0 = g_prof.get(); r.e1 = g_prof.get();
-    hipEventRecord(r.e0, s);
+    (void)hipEventRecord(r.e0, s);
   }
   ~ProfScope() {
     if (!active) return;
-    hipEventRecord(r.e1, s);
+    (void)hipEventRecord(r.e1, s);
     g_prof.recs.push_back(r);
   }
 };
@@ -467,22 +467,22 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
 }
 
 // ---------------------------------------------------------------------------------------------------
-static int adam_launch(float* p, const float* g, float* m, float* v, float* tgt, int64_t n, float lr, int step,
-                       float b1, float b2, float eps, float ema_beta, hipStream_t s) {
+static int adam_launch(float* p, const float* g, float* m, float* v, float* tgt, int64_t n, double lr, int step,
+                       double b1, double b2, double eps, double ema_beta, hipStream_t s) {
   if (n % 4) PORL_FAIL(PORL_ERR_INVALID, "adam range must be a multiple of 4 floats");
   if (step < 1) PORL_FAIL(PORL_ERR_INVALID, "adam step must be >= 1");
   // torch._single_tensor_adam: python doubles, rounded to fp32 where they meet tensors
-  const double bc1 = 1.0 - std::pow((double)b1, (double)step);
-  const double bc2 = 1.0 - std::pow((double)b2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
+  const double bc1 = 1.0 - std::pow(b1, (double)step);
+  const double bc2 = 1.0 - std::pow(b2, (double)step);
+  const float step_size = (float)(lr / bc1);
   const float bc2_sqrt = (float)std::sqrt(bc2);
-  const float omb1 = (float)(1.0 - (double)b1), omb2 = (float)(1.0 - (double)b2);
-  const float omeb = (float)(1.0 - (double)ema_beta);
+  const float omb1 = (float)(1.0 - b1), omb2 = (float)(1.0 - b2);
+  const float omeb = (float)(1.0 - ema_beta);
   const long n4 = n / 4;
   const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 2048);
   ProfScope ps("adam_ema_kernel", s, 0.0, (double)n * (tgt ? 36.0 : 28.0));
-  hipLaunchKernelGGL(adam_ema_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, tgt, n4, omb1, b2, omb2, eps,
-                     step_size, bc2_sqrt, ema_beta, omeb);
+  hipLaunchKernelGGL(adam_ema_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, tgt, n4, omb1, (float)b2, omb2,
+                     (float)eps, step_size, bc2_sqrt, (float)ema_beta, omeb);
   PORL_HIP(hipGetLastError());
   return PORL_OK;
 }
@@ -499,7 +499,7 @@ int porl_iql_policy_apply(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
   PORL_TRY(check_ready(h, false));
   if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
   return adam_launch(h->buf.params_pol, h->buf.grads_pol, h->buf.adam_m_pol, h->buf.adam_v_pol, nullptr, h->n_pol,
-                     hp->policy_lr, hp->policy_step, hp->adam_beta1, hp->adam_beta2, hp->adam_eps, 0.f,
+                     hp->policy_lr, hp->policy_step, hp->adam_beta1, hp->adam_beta2, hp->adam_eps, 0.0,
                      (hipStream_t)stream);
 }
 
@@ -744,8 +744,8 @@ int porl_gemm_f32(int mode, int tile, int32_t M, int32_t N, int32_t K, const flo
   return launch_group(g, tile, s);
 }
 
-int porl_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t n, float lr, int32_t step,
-                  float beta1, float beta2, float eps, float ema_beta, void* stream) {
+int porl_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t n, double lr, int32_t step,
+                  double beta1, double beta2, double eps, double ema_beta, void* stream) {
   if (!p || !g || !m || !v) PORL_FAIL(PORL_ERR_INVALID, "null buffer");
   if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (target && !aligned16(target)))
     PORL_FAIL(PORL_ERR_INVALID, "buffers must be 16-byte aligned");

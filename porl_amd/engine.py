@@ -15,12 +15,20 @@ import torch
 from . import _native as N
 
 
+def _norm_device(device):
+    """torch.device('cuda') and torch.device('cuda:0') must compare equal for the checks below."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 class IqlEngine:
     GROUP_VF, GROUP_POL = 0, 1
 
     def __init__(self, obs_dim, pol_out_dim, hidden_dim, n_hidden, layer_norm=False, pol_tanh=False,
                  weight_mode=0, max_batch=1024, device="cpu"):
-        self.device = torch.device(device)
+        self.device = _norm_device(device)
         self.cfg = N.IqlCfg(int(obs_dim), int(pol_out_dim), int(hidden_dim), int(n_hidden),
                             int(bool(layer_norm)), int(bool(pol_tanh)), int(weight_mode), int(max_batch))
         self._lib = N.lib()
@@ -59,7 +67,7 @@ class IqlEngine:
 
     def to(self, device):
         """Move every flat tensor; views handed out earlier must be re-created by the caller."""
-        device = torch.device(device)
+        device = _norm_device(device)
         if device == self.device:
             return self
         for name in ("params_vf", "params_tgt", "params_pol", "grads_vf", "grads_pol", "adam_m_vf",

