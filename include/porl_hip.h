@@ -161,6 +161,10 @@ int porl_gather_rows(const float* rows, int64_t row_stride, const int64_t* idx, 
 int porl_sample_indices(int64_t n_rows, int32_t batch, uint64_t seed, uint64_t step, int64_t base,
                         int64_t* out, void* stream);
 
+/* Experiment knobs (placement only, never results).  "gemm_lds_pad": extra dynamic LDS bytes per GEMM
+ * block, limiting how many blocks share a CU. */
+int porl_tune_set(const char* key, int value);
+
 /* Per-launch timing with HIP events on the launch stream (off by default; adds two event records per
  * kernel).  porl_prof_read synchronises the device and returns the number of entries filled. */
 typedef struct porl_prof_entry {

@@ -26,6 +26,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef PORL_ABL
+#define PORL_ABL 0     // timing-only ablations for scripts/gemm_abl.hip; 0 = the real kernel
+#endif
+
 namespace porl {
 
 enum : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
@@ -45,7 +49,7 @@ struct GemmProb {
   const float* bias;      // (N,) added before the activation, or null
   const float* mask;      // (M,N) ld=ldmask: C = acc * 1[mask > 0] (ReLU backward), or null
   const float* headw;     // (N,) fused scalar head: headout[part][m] = sum_n C(m,n)*headw[n]
-  float* headout;         // (parts, M) with parts = tiles_n * 2
+  float* headout;         // (parts, M) with parts = tiles_n * (waves along N), see head_parts()
   float* colsum;          // !A_KC only: (M,) column sums of A over K (bias gradient); slab s at +s*M
   const float* a_rowscale;  // APRO_RANK1_MASK
   const float* a_colscale;  // APRO_RANK1_MASK
@@ -70,9 +74,6 @@ struct GemmGroup {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GEMM_THREADS = 256;
-
-template <int BK>
 __host__ __device__ constexpr int lds_stride(int R) { return R + 4; }
 
 // Per-thread description of one staged float4 (4 consecutive elements of the operand's contiguous
@@ -85,30 +86,55 @@ struct StageSlot {
   int lds;            // LDS offset (floats) of element 0
 };
 
-// BM x BN block tile, 4 waves as 2(M) x 2(N), wave tile (BM/2) x (BN/2) made of 32x32 MFMA tiles.
+template <bool V> struct BoolTag { static constexpr bool value = V; };
+template <int V> struct IntTag { static constexpr int value = V; };
+
+#ifdef PORL_STAMP   // diagnostic builds only (scripts/gemm_abl.hip): shader clock vs 100 MHz real-time clock
+__device__ unsigned long long g_stamps[16 * 4096];   // per block: entry, loop begin, loop end, exit (100 MHz), cycles in loop, placement
+#endif
+
+// BM x BN block tile computed by WM x WN waves; each wave owns a (BM/WM) x (BN/WN) sub-tile made of
+// 32x32 MFMA tiles.  With 8 waves (two per SIMD) one wave's staging work (address arithmetic, LDS
+// writes, waits) runs under the other wave's MFMAs — with 4 waves the matrix pipe idles during it.
 //   VEC : every operand of every problem may be read with 16-byte loads (pointer, leading dimension
-//         and contiguous extent are multiples of 4 floats) — the fast path.  VEC=false reads dwords.
+//         and contiguous extent are multiples of 4 floats).  VEC=false reads dwords.
 //   APRO: A-operand prologue enabled (APRO_RANK1_MASK) for every problem of the group.
-template <int BM, int BN, int BK, bool VEC, bool APRO>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmGroup g) {
-  constexpr int WTM = BM / 64;            // MFMA tiles per wave along M
-  constexpr int WTN = BN / 64;
-  constexpr int SA = lds_stride<BK>(BM);
-  constexpr int SB = lds_stride<BK>(BN);
-  constexpr int A_TILE = BK * SA;
-  constexpr int B_TILE = BK * SB;
-  constexpr int NLA = BM * BK / 4 / GEMM_THREADS;   // float4 slots per thread per tile
-  constexpr int NLB = BN * BK / 4 / GEMM_THREADS;
-  static_assert(NLA >= 1 && NLB >= 1, "tile too small for 256 threads");
-  static_assert(BK % 4 == 0 && BM % 64 == 0 && BN % 64 == 0, "tile shape");
+// Blocks whose tile lies completely inside the problem (and whose K range is a whole number of
+// K-tiles) take an unguarded main loop; edge blocks take the guarded one.
+template <int BM, int BN, int BK, int WM, int WN, bool VEC, bool APRO>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup g) {
+  constexpr int THREADS = 64 * WM * WN;
+  constexpr int WTM = BM / WM / 32;       // MFMA tiles per wave along M
+  constexpr int WTN = BN / WN / 32;
+  // LDS images (per operand, per buffer):
+  //   m/n-contiguous source ("straight"): [BK][R + 4]   — copied, fragments read as dwords
+  //   k-contiguous source               : [R][BK + 4]   — copied too (no transpose), a lane reads the 4
+  //                                        k values of 4 consecutive MFMA steps with ONE ds_read_b128
+  // Both are written with ds_write_b128 and are bank-conflict free; any k order is legal for the
+  // MFMA as long as A and B agree, so the two halves of a wave take k = g*8 + {0..3} and g*8 + {4..7}.
+  constexpr int SA = lds_stride(BM);        // straight row stride
+  constexpr int SB = lds_stride(BN);
+  constexpr int SK = BK + 4;                // k-contiguous row stride
+  constexpr int A_TILE = (BK * SA > BM * SK) ? BK * SA : BM * SK;
+  constexpr int B_TILE = (BK * SB > BN * SK) ? BK * SB : BN * SK;
+  static_assert(BK % 8 == 0, "a k-group is 8 wide");
+  constexpr int NLA = BM * BK / 4 / THREADS;   // float4 slots per thread per tile
+  constexpr int NLB = BN * BK / 4 / THREADS;
+  static_assert(NLA >= 1 && NLB >= 1, "tile too small for the thread count");
+  static_assert(BM * BK / 4 % THREADS == 0 && BN * BK / 4 % THREADS == 0, "staging must divide evenly");
+  static_assert(BK % 4 == 0 && WTM >= 1 && WTN >= 1 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile shape");
 
   __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, kh = lane >> 5;
+#ifdef PORL_STAMP
+  unsigned long long rt_entry = 0, rt_loop0 = 0, rt_loop1 = 0, cy0 = 0, cy1 = 0, cy_barrier = 0, cy_store = 0, cy_load = 0;
+  if (t == 0) rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- XCD-aware block -> work mapping (blocks b, b+8, ... share an XCD / L2) ------------------
   int lin;
@@ -136,6 +162,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmGroup 
   const float* __restrict__ Bg = P.B;
   const bool a_kc = P.a_kc != 0, b_kc = P.b_kc != 0;   // wave-uniform (per problem)
   const bool do_colsum = (!a_kc) && (P.colsum != nullptr) && (tn == 0);
+  const bool full = VEC && (m0 + BM <= M) && (n0 + BN <= N) && ((ke - ks) % BK == 0);
+  // K-tiles are walked in natural order by every block.  (A per-block rotated order, tried to spread
+  // power-of-two row strides over L2 channels, cost 12 %: blocks of an XCD that share an operand panel
+  // stop touching the same lines at the same time and fall out of the 4 MiB L2.)
+  auto ktile = [&](int i) { return i; };
 
   // ---- staging slots -------------------------------------------------------------------------------
   StageSlot sa[NLA], sb[NLB];
@@ -146,10 +177,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmGroup 
   const size_t b_step = b_kc ? (size_t)BK : (size_t)BK * P.ldb;
 #pragma unroll
   for (int i = 0; i < NLA; ++i) {
-    const int f = t + GEMM_THREADS * i;
+    const int f = t + THREADS * i;
     if (a_kc) {
       const int kq = f % (BK / 4), row = f / (BK / 4);
-      sa[i].kpos = ks + kq * 4; sa[i].cpos = m0 + row; sa[i].lds = (kq * 4) * SA + row;
+      sa[i].kpos = ks + kq * 4; sa[i].cpos = m0 + row; sa[i].lds = row * SK + kq * 4;
       sa[i].ptr = Ag + (size_t)(m0 + row) * P.lda + (ks + kq * 4);
     } else {
       const int c4 = f % (BM / 4), kr = f / (BM / 4);
@@ -159,10 +190,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmGroup 
   }
 #pragma unroll
   for (int i = 0; i < NLB; ++i) {
-    const int f = t + GEMM_THREADS * i;
+    const int f = t + THREADS * i;
     if (b_kc) {
       const int kq = f % (BK / 4), row = f / (BK / 4);
-      sb[i].kpos = ks + kq * 4; sb[i].cpos = n0 + row; sb[i].lds = (kq * 4) * SB + row;
+      sb[i].kpos = ks + kq * 4; sb[i].cpos = n0 + row; sb[i].lds = row * SK + kq * 4;
       sb[i].ptr = Bg + (size_t)(n0 + row) * P.ldb + (ks + kq * 4);
     } else {
       const int c4 = f % (BN / 4), kr = f / (BN / 4);
@@ -171,122 +202,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmGroup 
     }
   }
 
-  // Guarded slot access without divergence.  `slot_ok` gives per-element validity for K-tile kt;
-  // `load_raw` issues the loads (out-of-range lanes read `safe`) and does NOT touch the result, so no
-  // wait is needed until `store_tile` zeroes the invalid elements and parks the tile in LDS.
-  auto slot_ok = [&](const StageSlot& s, int kadv, int dk, int dc, int cmax, bool (&ok)[4]) {
-    const int k = s.kpos + kadv;
-    if constexpr (VEC) {
-      ok[0] = ok[1] = ok[2] = ok[3] = (k < ke) && (s.cpos < cmax);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ok[j] = (k + j * dk < ke) && (s.cpos + j * dc < cmax);
-    }
-  };
-  auto load_raw = [&](const StageSlot& s, const float* __restrict__ safe, size_t off, const bool (&ok)[4]) -> float4 {
-    float4 v;
-    const float* p = s.ptr + off;
-    if constexpr (VEC) {
-      v = *reinterpret_cast<const float4*>(ok[0] ? p : safe);
-    } else {
-      v.x = *(ok[0] ? p : safe); v.y = *(ok[1] ? p + 1 : safe);
-      v.z = *(ok[2] ? p + 2 : safe); v.w = *(ok[3] ? p + 3 : safe);
-    }
-    return v;
-  };
-
-  float4 ra[NLA], rb[NLB];
-  float pr_rs[APRO ? NLA : 1];       // prologue row scale (one per slot)
-  float4 pr_cs[APRO ? NLA : 1];      // prologue column scales
-  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-
   // rank-1 prologue: element (k, c) of A becomes rowscale[b] * colscale[j] * 1[A > 0] where
   // (b, j) = (c, k) for k-contiguous A (dgrad) and (k, c) for m-contiguous A (wgrad); the 4 elements
   // of a slot always run along j (the contiguous, hidden dimension).
   const float* __restrict__ rsc = APRO ? P.a_rowscale : nullptr;
   const float* __restrict__ csc = APRO ? P.a_colscale : nullptr;
 
-  auto load_tile = [&](int kt) {
-    const int kadv = kt * BK;
-#pragma unroll
-    for (int i = 0; i < NLA; ++i) {
-      bool ok[4];
-      slot_ok(sa[i], kadv, a_dk, a_dc, M, ok);
-      ra[i] = load_raw(sa[i], Ag, (size_t)kt * a_step, ok);
-      if constexpr (APRO) {
-        const int k = sa[i].kpos + kadv, c = sa[i].cpos;
-        const int b0 = a_kc ? c : k, j0 = a_kc ? k : c;
-        pr_rs[i] = *(ok[0] ? rsc + b0 : rsc);
-        pr_cs[i].x = *(ok[0] ? csc + j0 : csc);
-        pr_cs[i].y = *(ok[1] ? csc + j0 + 1 : csc);
-        pr_cs[i].z = *(ok[2] ? csc + j0 + 2 : csc);
-        pr_cs[i].w = *(ok[3] ? csc + j0 + 3 : csc);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NLB; ++i) {
-      bool ok[4];
-      slot_ok(sb[i], kadv, b_dk, b_dc, N, ok);
-      rb[i] = load_raw(sb[i], Bg, (size_t)kt * b_step, ok);
-    }
-  };
-
-  // kt = the K-tile the registers hold
-  auto store_tile = [&](int kt) {
-    const int kadv = kt * BK;
-    float* As = lds + (kt & 1) * (A_TILE + B_TILE);
-    float* Bs = As + A_TILE;
-#pragma unroll
-    for (int i = 0; i < NLA; ++i) {
-      bool ok[4];
-      slot_ok(sa[i], kadv, a_dk, a_dc, M, ok);
-      float4 v = ra[i];
-      if constexpr (APRO) {
-        const float rs = pr_rs[i];
-        v.x = v.x > 0.f ? rs * pr_cs[i].x : 0.f;
-        v.y = v.y > 0.f ? rs * pr_cs[i].y : 0.f;
-        v.z = v.z > 0.f ? rs * pr_cs[i].z : 0.f;
-        v.w = v.w > 0.f ? rs * pr_cs[i].w : 0.f;
-      }
-      v.x = ok[0] ? v.x : 0.f; v.y = ok[1] ? v.y : 0.f; v.z = ok[2] ? v.z : 0.f; v.w = ok[3] ? v.w : 0.f;
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < NLB; ++i) {
-      bool ok[4];
-      slot_ok(sb[i], kadv, b_dk, b_dc, N, ok);
-      float4 v = rb[i];
-      v.x = ok[0] ? v.x : 0.f; v.y = ok[1] ? v.y : 0.f; v.z = ok[2] ? v.z : 0.f; v.w = ok[3] ? v.w : 0.f;
-      rb[i] = v;
-    }
-    if (a_kc) {
-#pragma unroll
-      for (int i = 0; i < NLA; ++i) {
-        As[sa[i].lds] = ra[i].x;
-        As[sa[i].lds + SA] = ra[i].y;
-        As[sa[i].lds + 2 * SA] = ra[i].z;
-        As[sa[i].lds + 3 * SA] = ra[i].w;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NLA; ++i) {
-        *reinterpret_cast<float4*>(As + sa[i].lds) = ra[i];
-        csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w;
-      }
-    }
-    if (b_kc) {
-#pragma unroll
-      for (int i = 0; i < NLB; ++i) {
-        Bs[sb[i].lds] = rb[i].x;
-        Bs[sb[i].lds + SB] = rb[i].y;
-        Bs[sb[i].lds + 2 * SB] = rb[i].z;
-        Bs[sb[i].lds + 3 * SB] = rb[i].w;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NLB; ++i) *reinterpret_cast<float4*>(Bs + sb[i].lds) = rb[i];
-    }
-  };
+  float4 ra[NLA], rb[NLB];
+  float pr_rs[APRO ? NLA : 1];       // prologue row scale (one per slot)
+  float4 pr_cs[APRO ? NLA : 1];      // prologue column scales
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 
   f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -296,59 +221,249 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmGroup 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (nkt > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
-  __syncthreads();
+  const int a_off = wm * (BM / WM) + li;
+  const int b_off = wn * (BN / WN) + li;
 
-  const int a_off = wm * (BM / 2) + li;
-  const int b_off = wn * (BN / 2) + li;
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    // tile kt+1 is requested before the MFMAs of tile kt and parked in LDS after them; past the last
-    // tile every lane is out of range, so the loads degenerate to reads of the operand base.
-    load_tile(kt + 1);
-    __builtin_amdgcn_sched_barrier(0);   // keep the global loads ahead of the MFMA block
-    const float* As = lds + (kt & 1) * (A_TILE + B_TILE);
+  // MFMAs of one K-tile, in k-groups of 8 (= 4 MFMA steps).  Fragments are double-buffered in
+  // registers: group g+1 is read from LDS while group g is multiplied.  `hook(g)` runs between two
+  // groups; the main loop uses it to park the next K-tile in LDS and to request the one after it in
+  // the shadow of the MFMAs.
+  auto compute = [&](int buf, auto akc_tag, auto bkc_tag, auto&& hook) {
+    constexpr bool AKC = decltype(akc_tag)::value, BKC = decltype(bkc_tag)::value;
+    constexpr int NG = BK / 8;
+    const float* As = lds + buf * (A_TILE + B_TILE);
     const float* Bs = As + A_TILE;
-    // fragments are double-buffered in registers: k-step kk+2 is read while kk is multiplied
-    float a[2][WTM], b[2][WTN];
+    float fa[2][WTM][4], fb[2][WTN][4];
+    auto read_group = [&](int g, int slot) {
 #pragma unroll
-    for (int i = 0; i < WTM; ++i) a[0][i] = As[kh * SA + a_off + i * 32];
+      for (int i = 0; i < WTM; ++i) {
+        if constexpr (AKC) {
+          const float4 v = *reinterpret_cast<const float4*>(As + (a_off + i * 32) * SK + g * 8 + kh * 4);
+          fa[slot][i][0] = v.x; fa[slot][i][1] = v.y; fa[slot][i][2] = v.z; fa[slot][i][3] = v.w;
+        } else {
 #pragma unroll
-    for (int j = 0; j < WTN; ++j) b[0][j] = Bs[kh * SB + b_off + j * 32];
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
-      if (kk + 2 < BK) {
-#pragma unroll
-        for (int i = 0; i < WTM; ++i) a[nxt][i] = As[(kk + 2 + kh) * SA + a_off + i * 32];
-#pragma unroll
-        for (int j = 0; j < WTN; ++j) b[nxt][j] = Bs[(kk + 2 + kh) * SB + b_off + j * 32];
+          for (int j = 0; j < 4; ++j) fa[slot][i][j] = As[(g * 8 + kh * 4 + j) * SA + a_off + i * 32];
+        }
       }
+#pragma unroll
+      for (int i = 0; i < WTN; ++i) {
+        if constexpr (BKC) {
+          const float4 v = *reinterpret_cast<const float4*>(Bs + (b_off + i * 32) * SK + g * 8 + kh * 4);
+          fb[slot][i][0] = v.x; fb[slot][i][1] = v.y; fb[slot][i][2] = v.z; fb[slot][i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb[slot][i][j] = Bs[(g * 8 + kh * 4 + j) * SB + b_off + i * 32];
+        }
+      }
+    };
+    read_group(0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int cur = g & 1;
+      if (g + 1 < NG) read_group(g + 1, cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);   // next fragments are requested before these MFMAs issue
 #pragma unroll
-      for (int i = 0; i < WTM; ++i)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < WTN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+          for (int n = 0; n < WTN; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][n][j], acc[i][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      hook(g);
       __builtin_amdgcn_sched_barrier(0);
     }
-    store_tile(kt + 1);
-    __syncthreads();
-  }
+  };
+
+  auto main_loop = [&](auto guard_tag, auto akc_tag, auto bkc_tag) {
+    constexpr bool GUARD = decltype(guard_tag)::value;
+    constexpr bool AKC = decltype(akc_tag)::value;
+
+    // per-element validity of a slot in K-tile kt (GUARD only)
+    auto slot_ok = [&](const StageSlot& s, int kadv, int dk, int dc, int cmax, bool (&ok)[4]) {
+      const int k = s.kpos + kadv;
+      if constexpr (VEC) {
+        ok[0] = ok[1] = ok[2] = ok[3] = (k < ke) && (s.cpos < cmax);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ok[j] = (k + j * dk < ke) && (s.cpos + j * dc < cmax);
+      }
+    };
+    // issue the loads of one slot; out-of-range lanes read `safe`; the result is not touched here, so
+    // no wait is needed until store_tile
+    auto load_raw = [&](const StageSlot& s, const float* __restrict__ safe, size_t off, const bool (&ok)[4]) -> float4 {
+      float4 v;
+      const float* p = s.ptr + off;
+      if constexpr (VEC) {
+        v = *reinterpret_cast<const float4*>(ok[0] ? p : safe);
+      } else {
+        v.x = *(ok[0] ? p : safe); v.y = *(ok[1] ? p + 1 : safe);
+        v.z = *(ok[2] ? p + 2 : safe); v.w = *(ok[3] ? p + 3 : safe);
+      }
+      return v;
+    };
+
+    auto load_tile = [&](int kt) {
+      const int kadv = kt * BK;
+#pragma unroll
+      for (int i = 0; i < NLA; ++i) {
+        bool ok[4] = {true, true, true, true};
+        if constexpr (GUARD) {
+          slot_ok(sa[i], kadv, a_dk, a_dc, M, ok);
+          ra[i] = load_raw(sa[i], Ag, (size_t)kt * a_step, ok);
+        } else {
+          ra[i] = *reinterpret_cast<const float4*>(sa[i].ptr + (size_t)kt * a_step);
+        }
+        if constexpr (APRO) {
+          const int k = sa[i].kpos + kadv, c = sa[i].cpos;
+          const int b0 = a_kc ? c : k, j0 = a_kc ? k : c;
+          if constexpr (GUARD) {
+            pr_rs[i] = *(ok[0] ? rsc + b0 : rsc);
+            pr_cs[i].x = *(ok[0] ? csc + j0 : csc);
+            pr_cs[i].y = *(ok[1] ? csc + j0 + 1 : csc);
+            pr_cs[i].z = *(ok[2] ? csc + j0 + 2 : csc);
+            pr_cs[i].w = *(ok[3] ? csc + j0 + 3 : csc);
+          } else {
+            pr_rs[i] = rsc[b0];
+            pr_cs[i] = *reinterpret_cast<const float4*>(csc + j0);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NLB; ++i) {
+        if constexpr (GUARD) {
+          bool ok[4];
+          slot_ok(sb[i], kadv, b_dk, b_dc, N, ok);
+          rb[i] = load_raw(sb[i], Bg, (size_t)kt * b_step, ok);
+        } else {
+          rb[i] = *reinterpret_cast<const float4*>(sb[i].ptr + (size_t)kt * b_step);
+        }
+      }
+    };
+
+    // kt = the K-tile the registers hold, buf = the LDS buffer it goes to
+    auto store_tile = [&](int kt, int buf) {
+      const int kadv = kt * BK;
+      float* As = lds + buf * (A_TILE + B_TILE);
+      float* Bs = As + A_TILE;
+#pragma unroll
+      for (int i = 0; i < NLA; ++i) {
+        float4 v = ra[i];
+        if constexpr (APRO) {
+          const float rs = pr_rs[i];
+          v.x = v.x > 0.f ? rs * pr_cs[i].x : 0.f;
+          v.y = v.y > 0.f ? rs * pr_cs[i].y : 0.f;
+          v.z = v.z > 0.f ? rs * pr_cs[i].z : 0.f;
+          v.w = v.w > 0.f ? rs * pr_cs[i].w : 0.f;
+        }
+        if constexpr (GUARD) {
+          bool ok[4];
+          slot_ok(sa[i], kadv, a_dk, a_dc, M, ok);
+          v.x = ok[0] ? v.x : 0.f; v.y = ok[1] ? v.y : 0.f; v.z = ok[2] ? v.z : 0.f; v.w = ok[3] ? v.w : 0.f;
+        }
+        ra[i] = v;
+      }
+      if constexpr (GUARD) {
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+          bool ok[4];
+          slot_ok(sb[i], kadv, b_dk, b_dc, N, ok);
+          float4 v = rb[i];
+          v.x = ok[0] ? v.x : 0.f; v.y = ok[1] ? v.y : 0.f; v.z = ok[2] ? v.z : 0.f; v.w = ok[3] ? v.w : 0.f;
+          rb[i] = v;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NLA; ++i) {
+        *reinterpret_cast<float4*>(As + sa[i].lds) = ra[i];
+        if constexpr (!AKC) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+      }
+#pragma unroll
+      for (int i = 0; i < NLB; ++i) *reinterpret_cast<float4*>(Bs + sb[i].lds) = rb[i];
+    };
+
+    // Workgroup barrier that does NOT drain outstanding global loads: LDS traffic is retired with
+    // lgkmcnt(0) only, the prefetch of K-tile kt+2 stays in flight across it.
+    auto lds_barrier = [&]() {
+#ifdef PORL_STAMP
+      const unsigned long long b0 = __builtin_amdgcn_s_memtime();
+#endif
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#ifdef PORL_STAMP
+      cy_barrier += __builtin_amdgcn_s_memtime() - b0;
+#endif
+    };
+
+    // Pipeline: while K-tile kt is multiplied, tile kt+1 (requested one iteration ago, long landed)
+    // moves registers -> LDS and tile kt+2 is requested.  The staging sits INSIDE the MFMA stream, and
+    // the two waves that share a SIMD (w, w+4) do it at different k-steps, so one of them always has
+    // MFMAs to issue while the other touches LDS.
+    auto iteration = [&](int it, auto split_tag) {
+      constexpr int SPLIT = decltype(split_tag)::value;
+      compute(it & 1, akc_tag, bkc_tag, [&](int kk) {
+        if (kk == SPLIT) {
+#ifdef PORL_STAMP
+          const unsigned long long h0 = __builtin_amdgcn_s_memtime();
+#endif
+          if (it + 1 < nkt) store_tile(ktile(it + 1), (it + 1) & 1);
+#ifdef PORL_STAMP
+          const unsigned long long h1 = __builtin_amdgcn_s_memtime();
+#endif
+          if (it + 2 < nkt) load_tile(ktile(it + 2));
+#ifdef PORL_STAMP
+          const unsigned long long h2 = __builtin_amdgcn_s_memtime();
+          cy_store += h1 - h0; cy_load += h2 - h1;
+#endif
+        }
+      });
+    };
+
+    if (nkt > 0) {
+      load_tile(ktile(0));
+      store_tile(ktile(0), 0);
+    }
+    if (nkt > 1) load_tile(ktile(1));
+    lds_barrier();
+    const bool early = wave < (WM * WN + 1) / 2;
+    for (int it = 0; it < nkt; ++it) {
+#if PORL_ABL == 5
+      iteration(it, IntTag<0>{});
+#else
+      if (early) iteration(it, IntTag<0>{});
+      else iteration(it, IntTag<BK / 16>{});
+#endif
+      lds_barrier();
+    }
+  };
+
+  // one specialised copy of the loop per operand-layout pair (uniform per block)
+  auto run = [&](auto guard_tag) {
+    if (a_kc && b_kc) {
+      if constexpr (!APRO) main_loop(guard_tag, BoolTag<true>{}, BoolTag<true>{});   // forward: no prologue user
+    } else if (a_kc) {
+      main_loop(guard_tag, BoolTag<true>{}, BoolTag<false>{});
+    } else {
+      main_loop(guard_tag, BoolTag<false>{}, BoolTag<false>{});
+    }
+  };
+  if (full) run(BoolTag<false>{});
+  else run(BoolTag<true>{});
+#ifdef PORL_STAMP
+  if (t == 0) { rt_loop1 = __builtin_amdgcn_s_memrealtime(); cy1 = __builtin_amdgcn_s_memtime(); }
+#endif
 
   // ---- bias gradient: column sums of A (only tn == 0 blocks), reduced through LDS --------------
-  // (csum also swallowed the all-zero phantom tile nkt, which adds nothing)
   if (do_colsum) {
+    __syncthreads();                                   // every wave is done reading the last K-tile
     float4* red = reinterpret_cast<float4*>(lds);
     red[t] = csum;
     __syncthreads();
     constexpr int C4 = BM / 4;                       // threads t, t+C4, ... share a column group
     if (t < C4) {
       float4 s = red[t];
-      for (int u = t + C4; u < GEMM_THREADS; u += C4) {
+      for (int u = t + C4; u < THREADS; u += C4) {
         const float4 o = red[u];
         s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
       }
@@ -373,16 +488,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmGroup 
     float hsum[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) hsum[r] = 0.f;
+    const int rbase = m0 + wm * (BM / WM) + i * 32 + 4 * kh;
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
-      const int col = n0 + wn * (BN / 2) + j * 32 + li;
+      const int col = n0 + wn * (BN / WN) + j * 32 + li;
       const bool col_ok = col < N;
       float bv = 0.f, hw = 0.f;
       if (!raw && col_ok) {
         if (P.bias) bv = P.bias[col];
         if (has_head) hw = P.headw[col];
       }
-      const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * kh;
       float vals[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -423,15 +538,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmGroup 
         hsum[r] = s;
       }
       if (li == 0) {
-        const int part = tn * 2 + wn;
+        const int part = tn * WN + wn;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * (BM / 2) + i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
           if (row < M) P.headout[(size_t)part * M + row] = hsum[r];
         }
       }
     }
   }
+#ifdef PORL_STAMP
+  __syncthreads();
+  if (t == 0 && blockIdx.x < 4096) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
+    unsigned long long* o = g_stamps + 16 * blockIdx.x;
+    o[0] = rt_entry; o[1] = rt_loop0; o[2] = rt_loop1; o[3] = __builtin_amdgcn_s_memrealtime();
+    o[4] = cy1 - cy0; o[5] = ((xcc & 0xF) << 12) | ((hwid >> 8) & 0xFFF);
+    o[6] = cy_barrier; o[7] = cy_store; o[8] = cy_load;
+  }
+  if (t == 256 && blockIdx.x < 4096) {   // a wave of the late half
+    unsigned long long* o = g_stamps + 16 * blockIdx.x;
+    o[9] = cy_barrier; o[10] = cy_store; o[11] = cy_load;
+  }
+#endif
 }
 
 // out[i] = act( sum_s slab[s*stride + i] + bias[i % ncols] )   (split-K combine, fixed order)
@@ -451,24 +581,33 @@ __global__ void slab_reduce_kernel(float* __restrict__ out, const float* __restr
 // host side
 // ---------------------------------------------------------------------------------------------------
 enum GemmMode : int { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
-enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_64x64 = 3 };
+enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_64x64 = 3,
+                      TILE_COUNT = 4 };
 
-constexpr int GEMM_BK = 16;
+constexpr int GEMM_BK = 32;
 
-inline void tile_dims(int tile, int& bm, int& bn) {
+// tile shape and wave grid of each configuration (the two large ones run 8 waves = 2 per SIMD)
+struct TileCfg { int bm, bn, wm, wn; };
+inline TileCfg tile_cfg(int tile) {
   switch (tile) {
-    case TILE_128x128: bm = 128; bn = 128; break;
-    case TILE_128x64: bm = 128; bn = 64; break;
-    case TILE_64x128: bm = 64; bn = 128; break;
-    default: bm = 64; bn = 64; break;
+    case TILE_128x128: return {128, 128, 2, 4};
+    case TILE_128x64: return {128, 64, 4, 2};
+    case TILE_64x128: return {64, 128, 2, 2};
+    default: return {64, 64, 2, 2};
   }
 }
 
-inline int head_parts(int N, int tile) {
-  int bm, bn;
-  tile_dims(tile, bm, bn);
-  return ((N + bn - 1) / bn) * 2;
+inline void tile_dims(int tile, int& bm, int& bn) {
+  const TileCfg c = tile_cfg(tile);
+  bm = c.bm; bn = c.bn;
 }
+
+// number of partial sums per row written by the fused scalar head
+inline int head_parts(int N, int tile) {
+  const TileCfg c = tile_cfg(tile);
+  return ((N + c.bn - 1) / c.bn) * c.wn;
+}
+constexpr int HEAD_PARTS_PER_64_COLS = 2;   // upper bound: parts <= ceil(N/64) * 2 for every tile config
 
 // Fill the planner fields; returns total blocks.
 inline int plan_group(GemmGroup& g, int tile) {
@@ -490,18 +629,23 @@ inline int plan_group(GemmGroup& g, int tile) {
   return start;
 }
 
-template <int BM, int BN>
+// Extra dynamic LDS per block (bytes): raises the group-segment size so that fewer blocks fit on a CU.
+// Purely a placement knob (the kernel never touches the extra bytes).
+inline int& gemm_lds_pad() { static int pad = 0; return pad; }
+
+template <int BM, int BN, int WM, int WN>
 inline hipError_t launch_tile(const GemmGroup& g, hipStream_t s) {
-  dim3 grid(g.total_blocks), block(GEMM_THREADS);
+  dim3 grid(g.total_blocks), block(64 * WM * WN);
+  const int pad = gemm_lds_pad();
   bool vec = true, apro = g.p[0].apro != APRO_NONE;
   for (int i = 0; i < g.nprob; ++i) {
     vec = vec && g.p[i].a_vec && g.p[i].b_vec;
     if ((g.p[i].apro != APRO_NONE) != apro) return hipErrorInvalidValue;   // a group shares the prologue
   }
-  if (vec && !apro) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, true, false>), grid, block, 0, s, g);
-  else if (vec && apro) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, true, true>), grid, block, 0, s, g);
-  else if (!apro) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, false, false>), grid, block, 0, s, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, false, true>), grid, block, 0, s, g);
+  if (vec && !apro) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, true, false>), grid, block, pad, s, g);
+  else if (vec && apro) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, true, true>), grid, block, pad, s, g);
+  else if (!apro) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, false, false>), grid, block, pad, s, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, false, true>), grid, block, pad, s, g);
   return hipGetLastError();
 }
 
@@ -510,10 +654,10 @@ inline hipError_t launch_gemm_group(int tile, GemmGroup& g, hipStream_t s) {
   if (g.nprob < 1 || g.nprob > MAX_GROUP) return hipErrorInvalidValue;
   if (plan_group(g, tile) == 0) return hipSuccess;
   switch (tile) {
-    case TILE_128x128: return launch_tile<128, 128>(g, s);
-    case TILE_128x64: return launch_tile<128, 64>(g, s);
-    case TILE_64x128: return launch_tile<64, 128>(g, s);
-    case TILE_64x64: return launch_tile<64, 64>(g, s);
+    case TILE_128x128: return launch_tile<128, 128, 2, 4>(g, s);
+    case TILE_128x64: return launch_tile<128, 64, 4, 2>(g, s);
+    case TILE_64x128: return launch_tile<64, 128, 2, 2>(g, s);
+    case TILE_64x64: return launch_tile<64, 64, 2, 2>(g, s);
   }
   return hipErrorInvalidValue;
 }

@@ -188,8 +188,10 @@ int launch_group(GemmGroup& g, int tile, hipStream_t s) {
     }
     int bm, bn;
     tile_dims(tile, bm, bn);
-    label = "gemm_f32_kernel<" + std::to_string(bm) + "," + std::to_string(bn) + ",16," + (vec ? "true" : "false") +
-            "," + (apro ? "true" : "false") + ">";
+    const TileCfg tc = tile_cfg(tile);
+    label = "gemm_f32_kernel<" + std::to_string(bm) + "," + std::to_string(bn) + "," + std::to_string(GEMM_BK) + "," +
+            std::to_string(tc.wm) + "," + std::to_string(tc.wn) + "," + (vec ? "true" : "false") + "," +
+            (apro ? "true" : "false") + ">";
   }
   ProfScope ps(label, s, flops, bytes);
   hipError_t e = launch_gemm_group(tile, g, s);
@@ -276,7 +278,8 @@ int porl_iql_create(const porl_iql_cfg* c, porl_iql** out) {
   h->n_pol = cur;
 
   h->Sp = (int)ru4(S); h->Dp = (int)ru4(D); h->Hp = (int)ru4(H);
-  h->parts_max = cdiv(H, 64) * 2;
+  h->parts_max = 0;
+  for (int tile = 0; tile < TILE_COUNT; ++tile) h->parts_max = std::max(h->parts_max, head_parts(H, tile));
   Workspace& w = h->ws;
   int64_t o = 0;
   auto take = [&](int64_t n) { int64_t r = o; o += ru4(n); return r; };
@@ -727,7 +730,7 @@ int porl_gemm_f32(int mode, int tile, int32_t M, int32_t N, int32_t K, const flo
   g.nprob = 1;
   g.p[0] = make_prob(mode, A, lda, B, ldb, C, ldc, M, N, K);
   if (tile < 0) tile = pick_tile(g);
-  if (tile > 3) PORL_FAIL(PORL_ERR_INVALID, "tile must be -1..3");
+  if (tile >= TILE_COUNT) PORL_FAIL(PORL_ERR_INVALID, "tile must be -1..%d", TILE_COUNT - 1);
   if (splitk > 1) {
     g.p[0].splitk = splitk; g.p[0].C = slab;
     PORL_TRY(launch_group(g, tile, s));
@@ -774,6 +777,12 @@ int porl_sample_indices(int64_t n_rows, int32_t batch, uint64_t seed, uint64_t s
                      seed, step, hb, base, out);
   PORL_HIP(hipGetLastError());
   return PORL_OK;
+}
+
+int porl_tune_set(const char* key, int value) {
+  if (!key) PORL_FAIL(PORL_ERR_INVALID, "null key");
+  if (!strcmp(key, "gemm_lds_pad")) { gemm_lds_pad() = std::max(0, value); return PORL_OK; }
+  PORL_FAIL(PORL_ERR_INVALID, "unknown tuning key '%s'", key);
 }
 
 int porl_prof_enable(int on) {

@@ -223,3 +223,7 @@ def prof_read(max_entries=64):
         N.check(n, "porl_prof_read")
     return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), total_ms=float(buf[i].total_ms),
                  flops=float(buf[i].flops), bytes=float(buf[i].bytes)) for i in range(n)]
+
+
+def tune_set(key, value):
+    N.check(N.lib().porl_tune_set(key.encode(), int(value)), "porl_tune_set")
