@@ -95,6 +95,20 @@ int porl_iql_load_batch(porl_iql* h, int32_t batch,
                         const float* pol_target, int64_t pt_rs,
                         void* stream);
 
+/* Same hand-over, but the minibatch is DRAWN on the device from a resident packed-row replay store
+ * (rows of [s(S) | r | s'(S) | d | a(A)], the wire format of por_train.py:74-78): row i of the batch is
+ * store row perm_{seed,step}(i) for a keyed bijection perm of [0, n_rows) — `batch` distinct rows, i.e.
+ * np.random.choice(size, B, replace=False) semantics (buffer/replay_buffer.py:64) without the O(N)
+ * host permutation or any host->device copy.  One kernel does draw + gather + split.  The policy target
+ * is s' (target_is_action = 0, POR) or the action columns (1, SORL).  idx_out (batch int64) may be NULL. */
+int porl_iql_load_batch_sampled(porl_iql* h, int32_t batch, const float* rows, int64_t row_stride,
+                                int64_t n_rows, int32_t act_dim, int32_t target_is_action,
+                                uint64_t seed, uint64_t step, int64_t* idx_out, void* stream);
+
+/* Redirect where the next updates write their 3 loss statistics (>= 8 floats, 16-byte aligned): lets a
+ * training loop keep a device-side loss history without copies or host syncs. */
+int porl_iql_set_stats(porl_iql* h, float* stats);
+
 typedef struct porl_iql_hyper {
   float tau;         /* expectile                                   */
   float discount;    /* gamma                                       */

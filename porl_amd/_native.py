@@ -18,6 +18,7 @@ SYMBOLS = [
     "porl_abi_version", "porl_last_error",
     "porl_iql_create", "porl_iql_destroy", "porl_iql_group_floats", "porl_iql_group_tensors",
     "porl_iql_tensor_info", "porl_iql_workspace_floats", "porl_iql_bind", "porl_iql_load_batch",
+    "porl_iql_load_batch_sampled", "porl_iql_set_stats",
     "porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_backward",
     "porl_iql_policy_apply", "porl_iql_step", "porl_iql_forward_value", "porl_iql_forward_policy",
     "porl_gemm_f32", "porl_adam_ema", "porl_gather_rows", "porl_sample_indices",
@@ -72,6 +73,8 @@ def _declare(lib):
     lib.porl_iql_workspace_floats.restype = i64
     lib.porl_iql_bind.argtypes = [vp, C.POINTER(IqlBuffers)]
     lib.porl_iql_load_batch.argtypes = [vp, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp]
+    lib.porl_iql_load_batch_sampled.argtypes = [vp, i32, vp, i64, i64, i32, i32, C.c_uint64, C.c_uint64, vp, vp]
+    lib.porl_iql_set_stats.argtypes = [vp, vp]
     for name in ("porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_backward",
                  "porl_iql_policy_apply", "porl_iql_step"):
         getattr(lib, name).argtypes = [vp, C.POINTER(IqlHyper), vp]

@@ -113,7 +113,7 @@ class IqlAgentBase(nn.Module):
         self._mods = (vf, v_target, policy)
         self._adopt(copy_from_modules=True)
         self._exchange = GradExchange()
-        self.async_losses = False     # True: return a (3,) device tensor instead of two host floats
+        self.async_losses = False     # True: return a (3,) device VIEW [v_loss, g_loss, min_nll], no host sync
 
     def _adopt(self, copy_from_modules=False):
         """Point every nn.Parameter at its view in the engine's flat tensors."""
@@ -158,9 +158,14 @@ class IqlAgentBase(nn.Module):
             adam_beta1=v_opt.param_groups[0]["betas"][0], adam_beta2=v_opt.param_groups[0]["betas"][1],
             adam_eps=v_opt.param_groups[0]["eps"])
 
-    def _full_update(self, obs, next_obs, rew, term, pol_target, v_opt, p_opt, sched):
+    def _full_update(self, obs, next_obs, rew, term, pol_target, v_opt, p_opt, sched, replay=None, batch=None):
         eng, ex = self._engine, self._exchange
-        B = eng.load_batch(obs, next_obs, rew, term, pol_target)
+        if replay is not None:
+            B = eng.load_batch_sampled(replay.rows, batch, replay.seed, replay.draws, replay.act_dim,
+                                       self._engine.cfg.weight_mode == 1)
+            replay.draws += 1
+        else:
+            B = eng.load_batch(obs, next_obs, rew, term, pol_target)
         v_opt.step_count += 1
         p_opt.step_count += 1
         hp = self._hyper(B, v_opt, p_opt)
@@ -191,7 +196,9 @@ class IqlAgentBase(nn.Module):
 
     def _losses(self):
         if self.async_losses:
-            return self._engine.stats[:3].clone()
+            # a VIEW of the engine's statistics buffer: no copy, no sync; the next update overwrites it
+            # unless the caller moved the buffer with engine.set_stats(...)
+            return self._engine.stats[:3]
         v_loss, g_loss, min_nlp = self._engine.stats[:3].tolist()     # the one host sync of the update
         if math.isnan(g_loss) or math.isnan(v_loss):
             # the reference fails earlier (MultivariateNormal validate_args -> ValueError)

@@ -58,3 +58,10 @@ class POR(IqlAgentBase):
         advantage-weighted goal-policy regression on s'.  Returns (v_loss, g_loss) as Python floats."""
         return agent._full_update(observations, next_observations, rewards, terminals, next_observations,
                                   agent.v_optimizer, agent.goal_policy_optimizer, agent.goal_lr_schedule)
+
+    def update_from_replay(agent, replay, batch_size):
+        """Extension (not in the reference): one POR step on `batch_size` distinct rows drawn on the device
+        from a `porl_amd.buffer.replay_buffer.PackedReplay` — sampling, gather and the update without any
+        host-side tensor work.  Same arithmetic as `por_residual_update` on those rows."""
+        return agent._full_update(None, None, None, None, None, agent.v_optimizer, agent.goal_policy_optimizer,
+                                  agent.goal_lr_schedule, replay=replay, batch=batch_size)

@@ -60,5 +60,10 @@ class SORL(IqlAgentBase):
         """Value step only (reference sorl.py:130-152) -> v_loss."""
         agent._value_update(observations, next_observations, rewards, terminals, agent.v_optimizer)
         if agent.async_losses:
-            return agent._engine.stats[:1].clone()
+            return agent._engine.stats[:1]
         return float(agent._engine.stats[0])
+
+    def update_from_replay(agent, replay, batch_size):
+        """Extension (not in the reference): `update` on rows drawn on the device from a PackedReplay."""
+        return agent._full_update(None, None, None, None, None, agent.v_optimizer, agent.policy_optimizer,
+                                  agent.lr_schedule, replay=replay, batch=batch_size)

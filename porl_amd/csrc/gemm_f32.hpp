@@ -51,6 +51,7 @@ struct GemmProb {
   const float* headw;     // (N,) fused scalar head: headout[part][m] = sum_n C(m,n)*headw[n]
   float* headout;         // (parts, M) with parts = tiles_n * (waves along N), see head_parts()
   float* colsum;          // !A_KC only: (M,) column sums of A over K (bias gradient); slab s at +s*M
+  float* rawdot;          // !A_KC + APRO only: (M,) sum_k rowscale[k] * A_raw(k, m)  (scalar-head weight gradient)
   const float* a_rowscale;  // APRO_RANK1_MASK
   const float* a_colscale;  // APRO_RANK1_MASK
   int M, N, K;
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
   float pr_rs[APRO ? NLA : 1];       // prologue row scale (one per slot)
   float4 pr_cs[APRO ? NLA : 1];      // prologue column scales
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 rdot = make_float4(0.f, 0.f, 0.f, 0.f);
 
   f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -349,17 +351,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
 #pragma unroll
       for (int i = 0; i < NLA; ++i) {
         float4 v = ra[i];
+        if constexpr (GUARD) {       // out-of-range lanes hold whatever sits at the operand base: zero them
+          bool ok[4];
+          slot_ok(sa[i], kadv, a_dk, a_dc, M, ok);
+          v.x = ok[0] ? v.x : 0.f; v.y = ok[1] ? v.y : 0.f; v.z = ok[2] ? v.z : 0.f; v.w = ok[3] ? v.w : 0.f;
+        }
         if constexpr (APRO) {
           const float rs = pr_rs[i];
+          if constexpr (!AKC) {      // wgrad blocks also accumulate dv^T H for the output-layer weight
+            rdot.x += rs * v.x; rdot.y += rs * v.y; rdot.z += rs * v.z; rdot.w += rs * v.w;
+          }
           v.x = v.x > 0.f ? rs * pr_cs[i].x : 0.f;
           v.y = v.y > 0.f ? rs * pr_cs[i].y : 0.f;
           v.z = v.z > 0.f ? rs * pr_cs[i].z : 0.f;
           v.w = v.w > 0.f ? rs * pr_cs[i].w : 0.f;
-        }
-        if constexpr (GUARD) {
-          bool ok[4];
-          slot_ok(sa[i], kadv, a_dk, a_dc, M, ok);
-          v.x = ok[0] ? v.x : 0.f; v.y = ok[1] ? v.y : 0.f; v.z = ok[2] ? v.z : 0.f; v.w = ok[3] ? v.w : 0.f;
         }
         ra[i] = v;
       }
@@ -458,21 +463,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
   if (do_colsum) {
     __syncthreads();                                   // every wave is done reading the last K-tile
     float4* red = reinterpret_cast<float4*>(lds);
-    red[t] = csum;
-    __syncthreads();
     constexpr int C4 = BM / 4;                       // threads t, t+C4, ... share a column group
-    if (t < C4) {
-      float4 s = red[t];
-      for (int u = t + C4; u < THREADS; u += C4) {
-        const float4 o = red[u];
-        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    auto reduce_cols = [&](const float4& mine, float* out) {
+      red[t] = mine;
+      __syncthreads();
+      if (t < C4) {
+        float4 s = red[t];
+        for (int u = t + C4; u < THREADS; u += C4) {
+          const float4 o = red[u];
+          s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        const int c = m0 + t * 4;
+        if (c < M) out[c] = s.x;
+        if (c + 1 < M) out[c + 1] = s.y;
+        if (c + 2 < M) out[c + 2] = s.z;
+        if (c + 3 < M) out[c + 3] = s.w;
       }
-      float* out = P.colsum + (size_t)split * M;
-      const int c = m0 + t * 4;
-      if (c < M) out[c] = s.x;
-      if (c + 1 < M) out[c + 1] = s.y;
-      if (c + 2 < M) out[c + 2] = s.z;
-      if (c + 3 < M) out[c + 3] = s.w;
+      __syncthreads();
+    };
+    reduce_cols(csum, P.colsum + (size_t)split * M);
+    if constexpr (APRO) {
+      if (P.rawdot) reduce_cols(rdot, P.rawdot + (size_t)split * M);
     }
   }
 

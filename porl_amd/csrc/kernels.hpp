@@ -55,14 +55,15 @@ struct ValueLossArgs {
   const float* b_t[2]; const float* b_v[2];     // scalar output biases (device pointers)
   const float* rew; const float* term;
   float* target_v; float* dv[2];
+  float* db_out[2];    // gradient of the scalar output bias: sum_b dv[b]
   float* stats;        // stats[0] = v_loss (this rank's share)
   int B, parts;
   float tau, discount, inv_batch;
 };
 
 __global__ __launch_bounds__(1024) void value_loss_kernel(const ValueLossArgs a) {
-  __shared__ float red[16];
-  float lsum = 0.f;
+  __shared__ float red[3][16];
+  float lsum = 0.f, d0sum = 0.f, d1sum = 0.f;
   const float bt0 = a.b_t[0][0], bt1 = a.b_t[1][0], bv0 = a.b_v[0][0], bv1 = a.b_v[1][0];
   for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
     float t0 = 0.f, t1 = 0.f, v0 = 0.f, v1 = 0.f;
@@ -77,17 +78,20 @@ __global__ __launch_bounds__(1024) void value_loss_kernel(const ValueLossArgs a)
     const float u0 = tgt - v0, u1 = tgt - v1;
     const float w0 = fabsf(a.tau - (u0 < 0.f ? 1.f : 0.f)), w1 = fabsf(a.tau - (u1 < 0.f ? 1.f : 0.f));
     lsum += 0.5f * (w0 * u0 * u0 + w1 * u1 * u1);
-    a.dv[0][b] = -w0 * u0 * a.inv_batch;
-    a.dv[1][b] = -w1 * u1 * a.inv_batch;
+    const float d0 = -w0 * u0 * a.inv_batch, d1 = -w1 * u1 * a.inv_batch;
+    a.dv[0][b] = d0;
+    a.dv[1][b] = d1;
+    d0sum += d0; d1sum += d1;
   }
-  lsum = wave_sum(lsum);
+  lsum = wave_sum(lsum); d0sum = wave_sum(d0sum); d1sum = wave_sum(d1sum);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) red[wave] = lsum;
+  if (lane == 0) { red[0][wave] = lsum; red[1][wave] = d0sum; red[2][wave] = d1sum; }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 3) {
     float s = 0.f;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
-    a.stats[0] = s * a.inv_batch;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[threadIdx.x][w];
+    if (threadIdx.x == 0) a.stats[0] = s * a.inv_batch;
+    else a.db_out[threadIdx.x - 1][0] = s;
   }
 }
 
@@ -260,24 +264,33 @@ __global__ __launch_bounds__(256) void policy_nll_kernel(const PolicyNllArgs a) 
   }
 }
 
-// stats[1] = g_loss, stats[2] = min nlp, grad(log_std) — one block, fixed order
+// stats[1] = g_loss, stats[2] = min nlp, grad(log_std).  One wave per log_std column (lanes stride over
+// the per-block partials, then a fixed-order wave reduction); the last block reduces loss and min.
+// grid = ceil(D / 4) + 1, block = 256
 __global__ __launch_bounds__(256) void policy_nll_finalize_kernel(const float* __restrict__ part_loss,
                                                                    const float* __restrict__ part_min,
                                                                    const float* __restrict__ part_dls, int nblk, int D,
                                                                    const float* __restrict__ log_std,
                                                                    float* __restrict__ g_log_std,
                                                                    float* __restrict__ stats) {
-  for (int j = threadIdx.x; j < D; j += blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += part_dls[(size_t)k * D + j];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (blockIdx.x + 1 == gridDim.x) {
+    if (wave == 0) {
+      float s = 0.f, m = INFINITY;
+      for (int k = lane; k < nblk; k += 64) { s += part_loss[k]; m = fminf(m, part_min[k]); }
+      s = wave_sum(s); m = wave_min(m);
+      if (lane == 0) { stats[1] = s; stats[2] = m; }
+    }
+    return;
+  }
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= D) return;
+  float s = 0.f;
+  for (int k = lane; k < nblk; k += 64) s += part_dls[(size_t)k * D + j];
+  s = wave_sum(s);
+  if (lane == 0) {
     const float ls = log_std[j];
     g_log_std[j] = (ls >= LOG_STD_MIN && ls <= LOG_STD_MAX) ? s : 0.f;   // clamp passes no gradient outside
-  }
-  if (threadIdx.x == 0) {
-    float s = 0.f, m = INFINITY;
-    for (int k = 0; k < nblk; ++k) { s += part_loss[k]; m = fminf(m, part_min[k]); }
-    stats[1] = s;
-    stats[2] = m;
   }
 }
 
@@ -400,17 +413,14 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   return x;
 }
 
-__global__ void sample_indices_kernel(int64_t n, int batch, uint64_t seed, uint64_t step, int hb,
-                                      int64_t base, int64_t* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= batch) return;
+__device__ __forceinline__ int64_t feistel_index(int64_t n, int i, uint64_t seed, uint64_t step, int hb) {
   const uint32_t mask = (1u << hb) - 1u;
   uint32_t keys[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     keys[r] = mix32((uint32_t)(seed >> (r & 1 ? 32 : 0)) ^ mix32((uint32_t)step * 4u + r) ^ (uint32_t)(step >> 30));
   uint64_t x = (uint64_t)i;
-  for (int iter = 0; iter < 64; ++iter) {          // expected < 4 walks (domain < 4n); bounded regardless
+  for (int iter = 0; iter < 64; ++iter) {
     uint32_t L = (uint32_t)(x >> hb) & mask, R = (uint32_t)x & mask;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -421,8 +431,45 @@ __global__ void sample_indices_kernel(int64_t n, int batch, uint64_t seed, uint6
     x = ((uint64_t)L << hb) | R;
     if ((int64_t)x < n) break;
   }
-  if ((int64_t)x >= n) x = (uint64_t)i;              // unreachable in practice; keeps the index legal
-  out[i] = base + (int64_t)x;
+  if ((int64_t)x >= n) x = (uint64_t)i;
+  return (int64_t)x;
+}
+
+// sampler + gather + split in one pass: batch row i <- packed replay row perm(i), written straight
+// into the step's dense buffers ([s | r | s' | d | a] wire format of por_train.py:74-78).
+// One wave per batch row.
+struct SampledBatchArgs {
+  const float* rows; long row_stride; int64_t n_rows;
+  int batch, S, A, D, Sp, Dp, hb, target_is_action;
+  uint64_t seed, step;
+  float* xs; float* xn; float* xt; float* rew; float* term;
+  int64_t* idx_out;      // optional: the drawn indices
+};
+
+__global__ __launch_bounds__(256) void sampled_batch_kernel(const SampledBatchArgs a) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= a.batch) return;
+  const int64_t r = feistel_index(a.n_rows, i, a.seed, a.step, a.hb);
+  const float* __restrict__ src = a.rows + r * a.row_stride;
+  const int S = a.S;
+  for (int c = lane; c < a.Sp; c += 64) {
+    a.xs[(size_t)i * a.Sp + c] = c < S ? src[c] : 0.f;
+    a.xn[(size_t)i * a.Sp + c] = c < S ? src[S + 1 + c] : 0.f;
+  }
+  const int toff = a.target_is_action ? 2 * S + 2 : S + 1;
+  for (int c = lane; c < a.Dp; c += 64) a.xt[(size_t)i * a.Dp + c] = c < a.D ? src[toff + c] : 0.f;
+  if (lane == 0) {
+    a.rew[i] = src[S];
+    a.term[i] = src[2 * S + 1];
+    if (a.idx_out) a.idx_out[i] = r;
+  }
+}
+
+__global__ void sample_indices_kernel(int64_t n, int batch, uint64_t seed, uint64_t step, int hb,
+                                      int64_t base, int64_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  out[i] = base + feistel_index(n, i, seed, step, hb);
 }
 
 }  // namespace porl

@@ -79,7 +79,7 @@ struct ProfScope {
 
 constexpr int NUM_CU = 256;
 constexpr int SK_MAX = 16;
-constexpr int NLL_ROWS_PER_BLOCK = 16;
+constexpr int NLL_ROWS_PER_BLOCK = 4;    // one row per wave
 
 inline int64_t ru4(int64_t x) { return (x + 3) & ~int64_t(3); }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -148,8 +148,12 @@ namespace {
 
 // ---- launch helpers -------------------------------------------------------------------------------
 int pick_tile(const GemmGroup& g) {
-  int minM = 1 << 30, minN = 1 << 30;
-  for (int i = 0; i < g.nprob; ++i) { minM = std::min(minM, g.p[i].M); minN = std::min(minN, g.p[i].N); }
+  int minM = 1 << 30, minN = 1 << 30, maxK = 0;
+  for (int i = 0; i < g.nprob; ++i) {
+    minM = std::min(minM, g.p[i].M); minN = std::min(minN, g.p[i].N); maxK = std::max(maxK, g.p[i].K);
+  }
+  // a short K loop cannot hide its own prologue/epilogue: many small blocks per CU overlap them instead
+  if (maxK <= 128) return TILE_64x64;
   auto blocks = [&](int tile) {
     int bm, bn, n = 0;
     tile_dims(tile, bm, bn);
@@ -298,7 +302,7 @@ int porl_iql_create(const porl_iql_cfg* c, porl_iql** out) {
   w.target_v = take(B);
   w.dmu = take((int64_t)B * h->Dp);
   w.slab_mean = take((int64_t)SK_MAX * B * h->Dp);
-  w.slab_a = take((int64_t)SK_MAX * 2 * ((int64_t)H * S + H + 8));
+  w.slab_a = take((int64_t)SK_MAX * 2 * ((int64_t)H * S + 2 * H + 8));
   w.slab_b = take((int64_t)SK_MAX * ((int64_t)D * H + D + 8));
   const int nblk = cdiv(B, NLL_ROWS_PER_BLOCK);
   w.part_loss = take(nblk); w.part_min = take(nblk); w.part_dls = take((int64_t)nblk * D);
@@ -365,6 +369,43 @@ int porl_iql_load_batch(porl_iql* h, int32_t batch, const float* obs, int64_t ob
   return PORL_OK;
 }
 
+static int feistel_half_bits(int64_t n_rows) {
+  int bits = 1;
+  while ((int64_t(1) << bits) < n_rows) ++bits;
+  return std::max(1, (bits + 1) / 2);
+}
+
+int porl_iql_load_batch_sampled(porl_iql* h, int32_t batch, const float* rows, int64_t row_stride, int64_t n_rows,
+                                int32_t act_dim, int32_t target_is_action, uint64_t seed, uint64_t step,
+                                int64_t* idx_out, void* stream) {
+  PORL_TRY(check_ready(h, false));
+  if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
+  if (!rows || n_rows < batch || n_rows > (int64_t(1) << 40)) PORL_FAIL(PORL_ERR_INVALID, "need batch <= n_rows");
+  const int S = h->cfg.obs_dim, D = h->cfg.pol_out_dim;
+  if (row_stride < 2 * (int64_t)S + 2 + act_dim) PORL_FAIL(PORL_ERR_INVALID, "row stride shorter than 2*S+2+A");
+  if (target_is_action ? D != act_dim : D != S) PORL_FAIL(PORL_ERR_INVALID, "policy target width mismatch");
+  float* W = h->buf.workspace;
+  SampledBatchArgs a{};
+  a.rows = rows; a.row_stride = (long)row_stride; a.n_rows = n_rows;
+  a.batch = batch; a.S = S; a.A = act_dim; a.D = D; a.Sp = h->Sp; a.Dp = h->Dp;
+  a.hb = feistel_half_bits(n_rows); a.target_is_action = target_is_action;
+  a.seed = seed; a.step = step;
+  a.xs = W + h->ws.xs; a.xn = W + h->ws.xn; a.xt = W + h->ws.xt; a.rew = W + h->ws.rew; a.term = W + h->ws.term;
+  a.idx_out = idx_out;
+  hipLaunchKernelGGL(sampled_batch_kernel, dim3(cdiv(batch, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  PORL_HIP(hipGetLastError());
+  h->batch = batch;
+  h->have_pol_target = true;
+  return PORL_OK;
+}
+
+int porl_iql_set_stats(porl_iql* h, float* stats) {
+  PORL_TRY(check_ready(h, false));
+  if (!stats) PORL_FAIL(PORL_ERR_INVALID, "null stats");
+  h->buf.stats = stats;
+  return PORL_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
   PORL_TRY(check_ready(h, true));
@@ -405,6 +446,7 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
       a.hp_t[i] = W + ws.hp_t[i]; a.hp_v[i] = W + ws.hp_v[i];
       a.b_t[i] = Pt + h->v[i].b[L]; a.b_v[i] = Pv + h->v[i].b[L];
       a.dv[i] = W + ws.dv[i];
+      a.db_out[i] = Gv + h->v[i].b[L];
     }
     a.rew = W + ws.rew; a.term = W + ws.term; a.target_v = W + ws.target_v; a.stats = h->buf.stats;
     a.B = B; a.parts = parts; a.tau = hp->tau; a.discount = hp->discount; a.inv_batch = hp->inv_batch;
@@ -412,17 +454,7 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
     PORL_HIP(hipGetLastError());
   }
 
-  // -- output layer gradient: dW_L = dv^T H_{L-1}, db_L = sum dv ------------------------------------------
-  {
-    HeadWgradArgs a{};
-    for (int i = 0; i < 2; ++i) {
-      a.H[i] = W + ws.act_v[i][L - 1]; a.dv[i] = W + ws.dv[i];
-      a.dW[i] = Gv + h->v[i].w[L]; a.db[i] = Gv + h->v[i].b[L];
-    }
-    a.B = B; a.Hdim = H; a.ld = Hp; a.nnets = 2;
-    hipLaunchKernelGGL(head_wgrad_kernel, dim3(cdiv(H, 64), 2), dim3(256), 0, s, a);
-    PORL_HIP(hipGetLastError());
-  }
+  // (output layer: db_L comes from the loss kernel, dW_L = dv^T H_{L-1} rides on the top wgrad's A loader)
 
   // -- hidden layers, top down.  dZ of the top layer is never materialised: it is the rank-1 prologue
   //    dv[b] * w_L[j] * 1[H_{L-1}[b,j] > 0] applied while staging H_{L-1}. ----------------------------
@@ -437,7 +469,10 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
       const int ldin = l == 0 ? h->Sp : Hp;
       GemmProb p = make_prob(GEMM_TN, dz, Hp, in, ldin, Gv + h->v[i].w[l], Kin, H, Kin, B);
       p.colsum = Gv + h->v[i].b[l];
-      if (top) { p.apro = APRO_RANK1_MASK; p.a_rowscale = W + ws.dv[i]; p.a_colscale = Pv + h->v[i].w[L]; }
+      if (top) {
+        p.apro = APRO_RANK1_MASK; p.a_rowscale = W + ws.dv[i]; p.a_colscale = Pv + h->v[i].w[L];
+        p.rawdot = Gv + h->v[i].w[L];
+      }
       g.p[g.nprob++] = p;
       if (l > 0) {
         GemmProb q = make_prob(GEMM_NN, dz, Hp, Pv + h->v[i].w[l], Kin, W + ws.dz_v[i][(l - 1) & 1], Hp, B, Kin, H);
@@ -455,11 +490,16 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
       if (sk > 1) {
         const int64_t per = (int64_t)H * Kin, perc = H;
         for (int i = 0; i < 2; ++i) {
-          float* slabW = W + ws.slab_a + (int64_t)i * SK_MAX * (per + perc + 8);
+          float* slabW = W + ws.slab_a + (int64_t)i * SK_MAX * (per + 2 * perc + 8);
           float* slabC = slabW + (int64_t)SK_MAX * per;
           g.p[i].splitk = sk; g.p[i].C = slabW; g.p[i].colsum = slabC;
           add_reduce(red, Gv + h->v[i].w[0], slabW, per, per, sk);
           add_reduce(red, Gv + h->v[i].b[0], slabC, perc, perc, sk);
+          if (g.p[i].rawdot) {   // single hidden layer: the head gradient is split the same way
+            float* slabR = slabC + (int64_t)SK_MAX * perc;
+            g.p[i].rawdot = slabR;
+            add_reduce(red, Gv + h->v[i].w[L], slabR, perc, perc, sk);
+          }
         }
       }
     }
@@ -577,7 +617,7 @@ int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream
     a.alpha = hp->alpha; a.inv_batch = hp->inv_batch; a.rows_per_block = NLL_ROWS_PER_BLOCK;
     hipLaunchKernelGGL(policy_nll_kernel, dim3(nblk), dim3(256), 0, s, a);
     PORL_HIP(hipGetLastError());
-    hipLaunchKernelGGL(policy_nll_finalize_kernel, dim3(1), dim3(256), 0, s, W + ws.part_loss, W + ws.part_min,
+    hipLaunchKernelGGL(policy_nll_finalize_kernel, dim3(cdiv(D, 4) + 1), dim3(256), 0, s, W + ws.part_loss, W + ws.part_min,
                        W + ws.part_dls, nblk, D, Pp + h->logstd_off, Gp + h->logstd_off, h->buf.stats);
     PORL_HIP(hipGetLastError());
   }
@@ -770,9 +810,7 @@ int porl_sample_indices(int64_t n_rows, int32_t batch, uint64_t seed, uint64_t s
                         void* stream) {
   if (n_rows < 1 || batch < 1 || batch > n_rows || !out) PORL_FAIL(PORL_ERR_INVALID, "need 1 <= batch <= n_rows");
   if (n_rows > (int64_t(1) << 40)) PORL_FAIL(PORL_ERR_INVALID, "n_rows too large");
-  int bits = 1;
-  while ((int64_t(1) << bits) < n_rows) ++bits;
-  const int hb = std::max(1, (bits + 1) / 2);
+  const int hb = feistel_half_bits(n_rows);
   hipLaunchKernelGGL(sample_indices_kernel, dim3(cdiv(batch, 256)), dim3(256), 0, (hipStream_t)stream, n_rows, batch,
                      seed, step, hb, base, out);
   PORL_HIP(hipGetLastError());

@@ -132,6 +132,24 @@ class IqlEngine:
             N.current_stream_ptr()), "porl_iql_load_batch")
         return B
 
+    def load_batch_sampled(self, rows, batch, seed, step, act_dim, target_is_action, idx_out=None):
+        """Draw `batch` distinct rows of a device-resident packed-row store and stage them (one kernel)."""
+        self._ensure_bound()
+        if rows.device != self.device or rows.dtype != torch.float32 or rows.dim() != 2 or rows.stride(1) != 1:
+            raise RuntimeError("replay rows must be a 2-D fp32 tensor on the engine's device")
+        N.check(self._lib.porl_iql_load_batch_sampled(
+            self._h, batch, N.ptr(rows), rows.stride(0), rows.shape[0], act_dim, int(target_is_action),
+            seed & 0xFFFFFFFFFFFFFFFF, step, N.ptr(idx_out), N.current_stream_ptr()), "porl_iql_load_batch_sampled")
+        return batch
+
+    def set_stats(self, stats):
+        """Point the loss statistics of the following updates at `stats` (>= 8 fp32 on the device)."""
+        self._ensure_bound()
+        if stats.device != self.device or stats.dtype != torch.float32 or stats.numel() < 8 or not stats.is_contiguous():
+            raise RuntimeError("stats must be >= 8 contiguous fp32 on the engine's device")
+        N.check(self._lib.porl_iql_set_stats(self._h, N.ptr(stats)), "porl_iql_set_stats")
+        self.stats = stats
+
     def hyper(self, **kw):
         d = dict(tau=0.9, discount=0.99, alpha=10.0, ema_beta=0.005, inv_batch=1.0, value_lr=1e-4,
                  policy_lr=1e-4, value_step=1, policy_step=1, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8)

@@ -249,3 +249,54 @@ def test_error_conventions():
         agent.por_residual_update(s[:32, :59], sp[:32], r[:32], d[:32])
     with pytest.raises(RuntimeError):                       # wrong device
         agent.por_residual_update(s[:32].cpu(), sp[:32], r[:32], d[:32])
+
+
+def test_update_from_replay_equals_update_on_the_drawn_rows():
+    """Device sampler + gather + split (one kernel) feeds the same arithmetic as the tensor API."""
+    from porl_amd.buffer.replay_buffer import PackedReplay
+    S, A, B, N = 60, 2, 128, 5000
+    rows = make_rows(N, S, A, seed=11)
+    a1, a2 = _make_por(S, 64, 2, B), _make_por(S, 64, 2, B)
+    rp = PackedReplay(rows, S, A, DEV, seed=3)
+    for step in range(3):
+        idx = torch.empty(B, dtype=torch.int64, device=DEV)
+        a1._engine.load_batch_sampled(rp.rows, B, rp.seed, rp.draws, A, False, idx_out=idx)   # peek at the draw
+        got = a1.update_from_replay(rp, B)
+        ih = idx.cpu().numpy()
+        assert len(set(ih.tolist())) == B and ih.min() >= 0 and ih.max() < N          # distinct, in range
+        batch = torch.from_numpy(rows[ih]).to(DEV)
+        s, r, sp, d, _ = split_rows(batch, S, A)
+        want = a2.por_residual_update(s, sp, r, d)
+        assert got == want
+    for (k, v1), v2 in zip(a1.state_dict().items(), a2.state_dict().values()):
+        assert torch.equal(v1, v2), k
+
+
+def test_device_sampler_is_a_uniform_permutation_prefix():
+    from porl_amd.engine import sample_indices
+    n, B = 1000, 1000
+    idx = sample_indices(n, B, seed=5, step=0, device=DEV).cpu().numpy()
+    assert sorted(idx.tolist()) == list(range(n))                # batch == n -> a permutation of all rows
+    # different steps / seeds give different draws; counts over many draws are flat
+    counts = np.zeros(97, dtype=np.int64)
+    for step in range(400):
+        counts += np.bincount(sample_indices(97, 10, seed=1, step=step, device=DEV).cpu().numpy(), minlength=97)
+    expect = 400 * 10 / 97
+    assert counts.min() > 0.5 * expect and counts.max() < 1.6 * expect
+    with pytest.raises(Exception):
+        sample_indices(10, 11, seed=0, step=0, device=DEV)        # B > size: like numpy's ValueError
+
+
+def test_stats_redirection_keeps_a_device_loss_history():
+    agent = _make_por(60, 64, 2, 32)
+    agent.async_losses = True
+    hist = torch.zeros(4, 8, device=DEV)
+    rows = torch.from_numpy(make_rows(4 * 32, 60, 2, seed=2)).to(DEV)
+    ref = _make_por(60, 64, 2, 32)
+    want = []
+    for k in range(4):
+        s, r, sp, d, a = split_rows(rows[k * 32:(k + 1) * 32], 60, 2)
+        agent._engine.set_stats(hist[k])
+        agent.por_residual_update(s, sp, r, d)
+        want.append(ref.por_residual_update(s, sp, r, d))
+    np.testing.assert_array_equal(hist[:, :2].cpu().numpy(), np.array(want, dtype=np.float32))
