@@ -42,31 +42,52 @@ def por_flops_per_sample():
 
 
 def cpu_baseline(budget_s=15.0):
-    """Numpy-oracle steps/s on the host, same shapes, bounded by wall time."""
+    """Numpy-oracle steps/s on the host, same shapes, bounded by wall time.  The BLAS thread count is
+    tuned first (a few trial steps per candidate) so the baseline is not handicapped by oversubscription."""
     import numpy as np
     from oracle.por_oracle import PorOracle
     from porl_amd.util.init import build_por_state_dict
     from porl_amd.util.synth import make_rows, split_rows
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        from threadpoolctl import threadpool_info, threadpool_limits
+        max_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
-        cores = os.cpu_count() or 1
+        threadpool_limits, max_threads = None, os.cpu_count() or 1
     o = PorOracle(build_por_state_dict(S, H, L, seed=0), S, H, L)
     rows = make_rows(8 * B, S, A, seed=0)
-    s, r, sp, d, _ = split_rows(rows[:B], S, A)
-    o.por_residual_update(s, sp, r, d)                       # warm-up (BLAS threads, page faults)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        k = (n + 1) % 8
-        s, r, sp, d, _ = split_rows(rows[k * B:(k + 1) * B], S, A)
-        o.por_residual_update(s, sp, r, d)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s and n >= 3:
-            break
-    return dict(value=n / el, unit="gradient-steps/sec", cores=int(cores), kind="port",
-                sample=f"{n} POR updates (B={B}, H={H}, S={S}) of oracle/por_oracle.py (numpy fp32, BLAS) in {el:.1f} s")
+
+    def steps(n, k0=0):
+        t0 = time.perf_counter()
+        for j in range(n):
+            k = (k0 + j) % 8
+            s, r, sp, d, _ = split_rows(rows[k * B:(k + 1) * B], S, A)
+            o.por_residual_update(s, sp, r, d)
+        return time.perf_counter() - t0
+
+    steps(1)                                                  # warm-up (BLAS threads, page faults)
+    best_t, best_rate = max_threads, 0.0
+    if threadpool_limits is not None:
+        for t in sorted({t for t in (8, 16, 32, 64, max_threads) if t <= max_threads}):
+            with threadpool_limits(limits=t):
+                steps(1)
+                rate = 2 / steps(2)
+            if rate > best_rate:
+                best_t, best_rate = t, rate
+    ctx = threadpool_limits(limits=best_t) if threadpool_limits is not None else None
+    try:
+        n, t0 = 0, time.perf_counter()
+        while True:
+            steps(1, n)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s and n >= 3:
+                break
+    finally:
+        if ctx is not None:
+            ctx.restore_original_limits() if hasattr(ctx, "restore_original_limits") else None
+    return dict(value=n / el, unit="gradient-steps/sec", cores=int(best_t), kind="port",
+                sample=f"{n} POR updates (B={B}, H={H}, S={S}) of oracle/por_oracle.py (numpy fp32, BLAS, "
+                       f"{best_t} threads = best of 8..{max_threads}) in {el:.1f} s")
 
 
 def main():

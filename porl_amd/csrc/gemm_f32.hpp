@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, kh = lane >> 5;
 #ifdef PORL_STAMP
-  unsigned long long rt_entry = 0, rt_loop0 = 0, rt_loop1 = 0, cy0 = 0, cy1 = 0, cy_barrier = 0, cy_store = 0, cy_load = 0;
+  unsigned long long rt_entry = 0, rt_loop0 = 0, rt_loop1 = 0, cy0 = 0, cy1 = 0, cy_barrier = 0, cy_store = 0, cy_load = 0, cy_group[4] = {0, 0, 0, 0};
   if (t == 0) rt_entry = __builtin_amdgcn_s_memrealtime();
 #endif
 
@@ -225,57 +225,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
 
   const int a_off = wm * (BM / WM) + li;
   const int b_off = wn * (BN / WN) + li;
-
-  // MFMAs of one K-tile, in k-groups of 8 (= 4 MFMA steps).  Fragments are double-buffered in
-  // registers: group g+1 is read from LDS while group g is multiplied.  `hook(g)` runs between two
-  // groups; the main loop uses it to park the next K-tile in LDS and to request the one after it in
-  // the shadow of the MFMAs.
-  auto compute = [&](int buf, auto akc_tag, auto bkc_tag, auto&& hook) {
-    constexpr bool AKC = decltype(akc_tag)::value, BKC = decltype(bkc_tag)::value;
-    constexpr int NG = BK / 8;
-    const float* As = lds + buf * (A_TILE + B_TILE);
-    const float* Bs = As + A_TILE;
-    float fa[2][WTM][4], fb[2][WTN][4];
-    auto read_group = [&](int g, int slot) {
-#pragma unroll
-      for (int i = 0; i < WTM; ++i) {
-        if constexpr (AKC) {
-          const float4 v = *reinterpret_cast<const float4*>(As + (a_off + i * 32) * SK + g * 8 + kh * 4);
-          fa[slot][i][0] = v.x; fa[slot][i][1] = v.y; fa[slot][i][2] = v.z; fa[slot][i][3] = v.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) fa[slot][i][j] = As[(g * 8 + kh * 4 + j) * SA + a_off + i * 32];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < WTN; ++i) {
-        if constexpr (BKC) {
-          const float4 v = *reinterpret_cast<const float4*>(Bs + (b_off + i * 32) * SK + g * 8 + kh * 4);
-          fb[slot][i][0] = v.x; fb[slot][i][1] = v.y; fb[slot][i][2] = v.z; fb[slot][i][3] = v.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) fb[slot][i][j] = Bs[(g * 8 + kh * 4 + j) * SB + b_off + i * 32];
-        }
-      }
-    };
-    read_group(0, 0);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int cur = g & 1;
-      if (g + 1 < NG) read_group(g + 1, cur ^ 1);
-      __builtin_amdgcn_sched_barrier(0);   // next fragments are requested before these MFMAs issue
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < WTM; ++i)
-#pragma unroll
-          for (int n = 0; n < WTN; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][n][j], acc[i][n], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      hook(g);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
 
   auto main_loop = [&](auto guard_tag, auto akc_tag, auto bkc_tag) {
     constexpr bool GUARD = decltype(guard_tag)::value;
@@ -387,42 +336,164 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
       for (int i = 0; i < NLB; ++i) *reinterpret_cast<float4*>(Bs + sb[i].lds) = rb[i];
     };
 
-    // Workgroup barrier that does NOT drain outstanding global loads: LDS traffic is retired with
-    // lgkmcnt(0) only, the prefetch of K-tile kt+2 stays in flight across it.
-    auto lds_barrier = [&]() {
-#ifdef PORL_STAMP
-      const unsigned long long b0 = __builtin_amdgcn_s_memtime();
-#endif
+    // single-slot versions used as fillers (q < NLA: A slot q, else B slot q - NLA)
+    auto load_slot_q = [&](int kt, int q) {
+      const int kadv = kt * BK;
+      if (q < NLA) {
+        const int i = q;
+        bool ok[4] = {true, true, true, true};
+        if constexpr (GUARD) {
+          slot_ok(sa[i], kadv, a_dk, a_dc, M, ok);
+          ra[i] = load_raw(sa[i], Ag, (size_t)kt * a_step, ok);
+        } else {
+          ra[i] = *reinterpret_cast<const float4*>(sa[i].ptr + (size_t)kt * a_step);
+        }
+        if constexpr (APRO) {
+          const int k = sa[i].kpos + kadv, c = sa[i].cpos;
+          const int b0 = a_kc ? c : k, j0 = a_kc ? k : c;
+          if constexpr (GUARD) {
+            pr_rs[i] = *(ok[0] ? rsc + b0 : rsc);
+            pr_cs[i].x = *(ok[0] ? csc + j0 : csc);
+            pr_cs[i].y = *(ok[1] ? csc + j0 + 1 : csc);
+            pr_cs[i].z = *(ok[2] ? csc + j0 + 2 : csc);
+            pr_cs[i].w = *(ok[3] ? csc + j0 + 3 : csc);
+          } else {
+            pr_rs[i] = rsc[b0];
+            pr_cs[i] = *reinterpret_cast<const float4*>(csc + j0);
+          }
+        }
+      } else {
+        const int i = q - NLA;
+        if constexpr (GUARD) {
+          bool ok[4];
+          slot_ok(sb[i], kadv, b_dk, b_dc, N, ok);
+          rb[i] = load_raw(sb[i], Bg, (size_t)kt * b_step, ok);
+        } else {
+          rb[i] = *reinterpret_cast<const float4*>(sb[i].ptr + (size_t)kt * b_step);
+        }
+      }
+    };
+    auto store_slot_q = [&](int kt, int buf, int q) {
+      const int kadv = kt * BK;
+      float* As = lds + buf * (A_TILE + B_TILE);
+      float* Bs = As + A_TILE;
+      if (q < NLA) {
+        const int i = q;
+        float4 v = ra[i];
+        if constexpr (GUARD) {
+          bool ok[4];
+          slot_ok(sa[i], kadv, a_dk, a_dc, M, ok);
+          v.x = ok[0] ? v.x : 0.f; v.y = ok[1] ? v.y : 0.f; v.z = ok[2] ? v.z : 0.f; v.w = ok[3] ? v.w : 0.f;
+        }
+        if constexpr (APRO) {
+          const float rs = pr_rs[i];
+          if constexpr (!AKC) {
+            rdot.x += rs * v.x; rdot.y += rs * v.y; rdot.z += rs * v.z; rdot.w += rs * v.w;
+          }
+          v.x = v.x > 0.f ? rs * pr_cs[i].x : 0.f;
+          v.y = v.y > 0.f ? rs * pr_cs[i].y : 0.f;
+          v.z = v.z > 0.f ? rs * pr_cs[i].z : 0.f;
+          v.w = v.w > 0.f ? rs * pr_cs[i].w : 0.f;
+        }
+        *reinterpret_cast<float4*>(As + sa[i].lds) = v;
+        if constexpr (!AKC) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
+      } else {
+        const int i = q - NLA;
+        float4 v = rb[i];
+        if constexpr (GUARD) {
+          bool ok[4];
+          slot_ok(sb[i], kadv, b_dk, b_dc, N, ok);
+          v.x = ok[0] ? v.x : 0.f; v.y = ok[1] ? v.y : 0.f; v.z = ok[2] ? v.z : 0.f; v.w = ok[3] ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(Bs + sb[i].lds) = v;
+      }
+    };
+
+    // ------------------------------------------------------------------------------------------
+    // Main loop: ONE wave per SIMD, paced by the matrix pipe.  A K-tile is NG k-groups of 8 (4 MFMA
+    // steps each); everything that is not an MFMA is issued as a FILLER in the shadow of an MFMA
+    // (an f32 32x32x2 MFMA keeps the pipe busy for 64 cycles but needs only a few issue cycles):
+    //   group 0   : request K-tile it+1 from global memory (registers are free: parked last iteration)
+    //   group g   : read the fragments of group g+1 from LDS
+    //   group NG-2: park K-tile it+1 in the other LDS buffer (its loads are >= one group old)
+    //   group NG-1: half way, workgroup barrier; then read group 0 of the NEXT tile, so the first MFMAs
+    //               after the barrier already have their operands
+    // sched_barrier(0) pins every filler behind its MFMA; waits are inserted by the compiler at first use.
+    // ------------------------------------------------------------------------------------------
+    constexpr bool BKC = decltype(bkc_tag)::value;
+    constexpr int NG = BK / 8;
+    constexpr int MG = 4 * WTM * WTN;           // MFMAs per k-group per wave
+    static_assert(NG >= 3, "schedule needs at least 3 k-groups per K-tile");
+    static_assert(MG >= 2, "a k-group has at least two MFMAs");
+    float fa[2][WTM][4], fb[2][WTN][4];
+
+    // one fragment-read unit of k-group g of LDS buffer buf.  Units 0..2*WTM-1 cover A (block u/2, k-half
+    // u%2), the rest B.  A k-contiguous image is read with ds_read_b64 (two k per lane: measured at ~12
+    // added cycles per instruction between f32 MFMAs, against ~45 for ds_read_b128 and ~40 for
+    // ds_read_b32, scripts/mfma_fill.hip); lane half kh takes k = g*8 + kh*4 + {0..3}.
+    auto read_unit = [&](int buf, int g, int slot, int u) {
+      const float* As = lds + buf * (A_TILE + B_TILE);
+      const float* Bs = As + A_TILE;
+      if (u < 2 * WTM) {
+        const int i = u >> 1, hf = u & 1;
+        if constexpr (AKC) {
+          const float2 v = *reinterpret_cast<const float2*>(As + (a_off + i * 32) * SK + g * 8 + kh * 4 + hf * 2);
+          fa[slot][i][hf * 2] = v.x; fa[slot][i][hf * 2 + 1] = v.y;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) fa[slot][i][hf * 2 + j] = As[(g * 8 + kh * 4 + hf * 2 + j) * SA + a_off + i * 32];
+        }
+      } else {
+        const int i = (u - 2 * WTM) >> 1, hf = u & 1;
+        if constexpr (BKC) {
+          const float2 v = *reinterpret_cast<const float2*>(Bs + (b_off + i * 32) * SK + g * 8 + kh * 4 + hf * 2);
+          fb[slot][i][hf * 2] = v.x; fb[slot][i][hf * 2 + 1] = v.y;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) fb[slot][i][hf * 2 + j] = Bs[(g * 8 + kh * 4 + hf * 2 + j) * SB + b_off + i * 32];
+        }
+      }
+    };
+    constexpr int NRU = 2 * (WTM + WTN);       // fragment-read units per group
+    constexpr int NLD = NLA + NLB;             // staging slots per tile
+
+    auto wg_barrier = [&]() {
+      // LDS traffic is retired with lgkmcnt(0) only: global loads in flight are NOT drained
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-#ifdef PORL_STAMP
-      cy_barrier += __builtin_amdgcn_s_memtime() - b0;
-#endif
     };
 
-    // Pipeline: while K-tile kt is multiplied, tile kt+1 (requested one iteration ago, long landed)
-    // moves registers -> LDS and tile kt+2 is requested.  The staging sits INSIDE the MFMA stream, and
-    // the two waves that share a SIMD (w, w+4) do it at different k-steps, so one of them always has
-    // MFMAs to issue while the other touches LDS.
-    auto iteration = [&](int it, auto split_tag) {
-      constexpr int SPLIT = decltype(split_tag)::value;
-      compute(it & 1, akc_tag, bkc_tag, [&](int kk) {
-        if (kk == SPLIT) {
-#ifdef PORL_STAMP
-          const unsigned long long h0 = __builtin_amdgcn_s_memtime();
-#endif
-          if (it + 1 < nkt) store_tile(ktile(it + 1), (it + 1) & 1);
-#ifdef PORL_STAMP
-          const unsigned long long h1 = __builtin_amdgcn_s_memtime();
-#endif
-          if (it + 2 < nkt) load_tile(ktile(it + 2));
-#ifdef PORL_STAMP
-          const unsigned long long h2 = __builtin_amdgcn_s_memtime();
-          cy_store += h1 - h0; cy_load += h2 - h1;
-#endif
-        }
-      });
+    // fillers of (group g, MFMA index m within the group); items are spread evenly over half a group
+    //   g = 0 : park tile it+1 (requested during the previous iteration) in the free LDS buffer
+    //   g = 1 : request tile it+2 into the same staging registers  (>= 2.5 groups ahead of its use)
+    //   every g: read the fragments of group g+1;  g = NG-1: barrier, then group 0 of the next tile
+    auto filler = [&](int it, int g, int m, bool has_next, bool has_next2) {
+      const int buf = it & 1;
+      auto span = [&](int n_items, int first_m, int last_m, int& lo, int& hi) {   // items for MFMA m
+        const int w = last_m - first_m;                                           // slots available
+        if (m < first_m || m >= last_m) { lo = hi = 0; return; }
+        lo = (m - first_m) * n_items / w; hi = (m - first_m + 1) * n_items / w;
+      };
+      int lo, hi;
+      if (g == 0) {
+        span(NLD, 0, MG / 2, lo, hi);
+        if (has_next)
+          for (int q = lo; q < hi; ++q) store_slot_q(ktile(it + 1), buf ^ 1, q);
+      } else if (g == 1) {
+        span(NLD, 0, MG / 2, lo, hi);
+        if (has_next2)
+          for (int q = lo; q < hi; ++q) load_slot_q(ktile(it + 2), q);
+      }
+      if (g < NG - 1) {
+        span(NRU, MG / 2, MG, lo, hi);
+        for (int q = lo; q < hi; ++q) read_unit(buf, g + 1, (g + 1) & 1, q);
+      } else {
+        if (m == MG / 2 - 1) wg_barrier();
+        span(NRU, MG / 2, MG, lo, hi);
+        if (has_next)
+          for (int q = lo; q < hi; ++q) read_unit(buf ^ 1, 0, 0, q);
+      }
     };
 
     if (nkt > 0) {
@@ -430,17 +501,43 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
       store_tile(ktile(0), 0);
     }
     if (nkt > 1) load_tile(ktile(1));
-    lds_barrier();
-    const bool early = wave < (WM * WN + 1) / 2;
-    for (int it = 0; it < nkt; ++it) {
-#if PORL_ABL == 5
-      iteration(it, IntTag<0>{});
-#else
-      if (early) iteration(it, IntTag<0>{});
-      else iteration(it, IntTag<BK / 16>{});
+    wg_barrier();
+#pragma unroll
+    for (int u = 0; u < NRU; ++u) read_unit(0, 0, 0, u);
+
+    // the body is instantiated twice — with and without a following tile — so that no filler sits
+    // behind a branch (a branch would make the compiler drain vmcnt before every request)
+    auto iteration = [&](int it, auto next_tag, auto next2_tag) {
+      constexpr bool HAS_NEXT = decltype(next_tag)::value, HAS_NEXT2 = decltype(next2_tag)::value;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int cur = g & 1;
+#ifdef PORL_STAMP
+        const unsigned long long gs = __builtin_amdgcn_s_memtime();
 #endif
-      lds_barrier();
-    }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int n = 0; n < WTN; ++n) {
+#if PORL_ABL == 6     // timing-only: no matrix work (fragments are still read and kept alive)
+              asm volatile("" :: "v"(fa[cur][i][j]), "v"(fb[cur][n][j]));
+#else
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][n][j], acc[i][n], 0, 0, 0);
+#endif
+              __builtin_amdgcn_sched_barrier(0);
+              filler(it, g, (j * WTM + i) * WTN + n, HAS_NEXT, HAS_NEXT2);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#ifdef PORL_STAMP
+        cy_group[g & 3] += __builtin_amdgcn_s_memtime() - gs;
+#endif
+      }
+    };
+    for (int it = 0; it + 2 < nkt; ++it) iteration(it, BoolTag<true>{}, BoolTag<true>{});
+    if (nkt > 1) iteration(nkt - 2, BoolTag<true>{}, BoolTag<false>{});
+    if (nkt > 0) iteration(nkt - 1, BoolTag<false>{}, BoolTag<false>{});
   };
 
   // one specialised copy of the loop per operand-layout pair (uniform per block)
@@ -566,11 +663,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
     unsigned long long* o = g_stamps + 16 * blockIdx.x;
     o[0] = rt_entry; o[1] = rt_loop0; o[2] = rt_loop1; o[3] = __builtin_amdgcn_s_memrealtime();
     o[4] = cy1 - cy0; o[5] = ((xcc & 0xF) << 12) | ((hwid >> 8) & 0xFFF);
-    o[6] = cy_barrier; o[7] = cy_store; o[8] = cy_load;
-  }
-  if (t == 256 && blockIdx.x < 4096) {   // a wave of the late half
-    unsigned long long* o = g_stamps + 16 * blockIdx.x;
-    o[9] = cy_barrier; o[10] = cy_store; o[11] = cy_load;
+    o[6] = cy_group[0]; o[7] = cy_group[1]; o[8] = cy_group[2]; o[9] = cy_group[3];
   }
 #endif
 }
@@ -597,12 +690,12 @@ enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_6
 
 constexpr int GEMM_BK = 32;
 
-// tile shape and wave grid of each configuration (the two large ones run 8 waves = 2 per SIMD)
+// tile shape and wave grid of each configuration (4 waves = one per SIMD, MFMA-paced with fillers)
 struct TileCfg { int bm, bn, wm, wn; };
 inline TileCfg tile_cfg(int tile) {
   switch (tile) {
-    case TILE_128x128: return {128, 128, 2, 4};
-    case TILE_128x64: return {128, 64, 4, 2};
+    case TILE_128x128: return {128, 128, 2, 2};
+    case TILE_128x64: return {128, 64, 2, 2};
     case TILE_64x128: return {64, 128, 2, 2};
     default: return {64, 64, 2, 2};
   }
@@ -665,8 +758,8 @@ inline hipError_t launch_gemm_group(int tile, GemmGroup& g, hipStream_t s) {
   if (g.nprob < 1 || g.nprob > MAX_GROUP) return hipErrorInvalidValue;
   if (plan_group(g, tile) == 0) return hipSuccess;
   switch (tile) {
-    case TILE_128x128: return launch_tile<128, 128, 2, 4>(g, s);
-    case TILE_128x64: return launch_tile<128, 64, 4, 2>(g, s);
+    case TILE_128x128: return launch_tile<128, 128, 2, 2>(g, s);
+    case TILE_128x64: return launch_tile<128, 64, 2, 2>(g, s);
     case TILE_64x128: return launch_tile<64, 128, 2, 2>(g, s);
     case TILE_64x64: return launch_tile<64, 64, 2, 2>(g, s);
   }

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 M, N, K = 4096, 1024, 1024
-names = {0: "real (staggered)", 5: "no stagger"}
+names = {0: "real", 6: "no MFMA (memory pipeline only)"}
 for tile in (0, 3):
     for mode, mname in ((0, "NT"), (2, "TN")):
         A = torch.randn((M, K) if mode < 2 else (K, M), device="cuda")
@@ -25,8 +25,8 @@ for tile in (0, 3):
             print(f"tile{tile} {mname} abl={abl} {names[abl]:22s}: {us:7.1f} us {2.0*M*N*K/us/1e6:7.1f} TF")
 
 
+
 import numpy as np
-print("CUs:", torch.cuda.get_device_properties(0).multi_processor_count)
 lib = C.CDLL(os.path.join(HERE, "_abl", "libabl_stamp_0.so"))
 f = lib.abl_gemm
 f.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -39,16 +39,6 @@ buf = np.zeros(16 * 256, dtype=np.uint64)
 lib.abl_stamps.argtypes = [C.c_void_p, C.c_int]
 lib.abl_stamps(buf.ctypes.data, buf.size)
 s = buf.reshape(-1, 16).astype(np.float64)
-t0 = s[:, 0].min()
-ns = lambda x: x * 10.0
-print(f"entry spread        : {ns(s[:,0].max()-t0):.0f} ns")
-print(f"setup (entry->loop) : median {ns(np.median(s[:,1]-s[:,0])):.0f} ns")
-print(f"main loop           : median {ns(np.median(s[:,2]-s[:,1])):.0f} ns  min {ns((s[:,2]-s[:,1]).min()):.0f} max {ns((s[:,2]-s[:,1]).max()):.0f};  cycles median {np.median(s[:,4]):.0f} -> {np.median(s[:,4]/(s[:,2]-s[:,1]))*0.1:.3f} GHz")
-print(f"epilogue (loop->exit): median {ns(np.median(s[:,3]-s[:,2])):.0f} ns max {ns((s[:,3]-s[:,2]).max()):.0f}")
-print(f"first exit / last exit after first entry: {ns(s[:,3].min()-t0):.0f} / {ns(s[:,3].max()-t0):.0f} ns")
-place = s[:, 5].astype(np.int64)
-from collections import Counter
-print("distinct placements:", len(set(place.tolist())), " blocks per XCC:", sorted(Counter((place >> 12).tolist()).items()))
-
 nk = K // 32
-print(f"per K-tile cycles (wave 0 / wave 4): loop {np.median(s[:,4])/nk:.0f};  barrier {np.median(s[:,6])/nk:.0f} / {np.median(s[:,9])/nk:.0f};  store {np.median(s[:,7])/nk:.0f} / {np.median(s[:,10])/nk:.0f};  load-issue {np.median(s[:,8])/nk:.0f} / {np.median(s[:,11])/nk:.0f}")
+print(f"main loop: median {np.median(s[:,2]-s[:,1])*10:.0f} ns; cycles/K-tile {np.median(s[:,4])/nk:.0f}; clock {np.median(s[:,4]/(s[:,2]-s[:,1]))*0.1:.3f} GHz; setup {np.median(s[:,1]-s[:,0])*10:.0f} ns; epilogue {np.median(s[:,3]-s[:,2])*10:.0f} ns")
+print("cycles per K-tile by k-group (ideal 1024 each):", [round(float(np.median(s[:, 6 + g]) / nk)) for g in range(4)])

@@ -10,7 +10,7 @@ extern "C" int abl_gemm(int mode, int M, int N, int K, const float* A, int lda, 
   const TileCfg c = tile_cfg(ABL_TILE);
   dim3 grid(g.total_blocks), block(64 * c.wm * c.wn);
 #if ABL_TILE == 0
-  hipLaunchKernelGGL((gemm_f32_kernel<128, 128, GEMM_BK, 2, 4, true, false>), grid, block, 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<128, 128, GEMM_BK, 2, 2, true, false>), grid, block, 0, (hipStream_t)stream, g);
 #else
   hipLaunchKernelGGL((gemm_f32_kernel<64, 64, GEMM_BK, 2, 2, true, false>), grid, block, 0, (hipStream_t)stream, g);
 #endif
