@@ -147,6 +147,68 @@ int porl_iql_forward_policy(porl_iql* h, const float* x, int64_t x_rs, int32_t b
                             int64_t mean_rs, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Discrete-action Q-network engine: CQL(H) on a plain-DQN TD target
+ * (CQLTrainer.learn / compute_cql_penalty, src/porl/train/cql_trainer.py:60-124; QNetwork,
+ * src/porl/net/q_network.py:8-30; hard target sync, src/porl/train/dqn_trainer.py:195-196).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct porl_qnet_cfg {
+  int32_t state_dim;
+  int32_t n_actions;                 /* <= 64 */
+  int32_t n_hidden;                  /* QNetwork default: 3 */
+  int32_t hidden[PORL_MAX_HIDDEN];   /* QNetwork default: 64, 128, 64 */
+  int32_t max_batch;
+} porl_qnet_cfg;
+
+typedef struct porl_qnet porl_qnet;
+
+typedef struct porl_qnet_buffers {
+  float* params;      /* online net, porl_qnet_param_floats() floats: per Linear weight (out,in), bias (out) */
+  float* params_tgt;  /* target net, same layout */
+  float* grads;
+  float* adam_m;
+  float* adam_v;
+  float* workspace;   /* porl_qnet_workspace_floats() floats */
+  float* stats;       /* >= 8 floats: [0] loss, [1] td loss, [2] cql penalty */
+} porl_qnet_buffers;
+
+typedef struct porl_qnet_hyper {
+  float gamma;        /* discount */
+  float alpha;        /* penalty weight (cql_trainer.py:42, default 1) */
+  float inv_batch;    /* 1/B_global */
+  int32_t step;       /* Adam step counter t >= 1 */
+  double lr;          /* dqn_trainer.py:71: 5e-4 */
+  double adam_beta1, adam_beta2, adam_eps;
+} porl_qnet_hyper;
+
+int porl_qnet_create(const porl_qnet_cfg* cfg, porl_qnet** out);
+void porl_qnet_destroy(porl_qnet* h);
+int64_t porl_qnet_param_floats(const porl_qnet* h);
+int32_t porl_qnet_tensors(const porl_qnet* h);
+int porl_qnet_tensor_info(const porl_qnet* h, int index, int64_t* offset, int32_t* rows, int32_t* cols);
+int64_t porl_qnet_workspace_floats(const porl_qnet* h);
+int porl_qnet_bind(porl_qnet* h, const porl_qnet_buffers* bufs);
+/* The five tensors ReplayBuffer.sample returns (buffer/replay_buffer.py:53-75); *_rs = row / element
+ * strides; actions are int64.  Any of actions / rewards / next_states / dones may be NULL for
+ * forward-only use. */
+int porl_qnet_load_batch(porl_qnet* h, int32_t batch, const float* states, int64_t s_rs,
+                         const int64_t* actions, int64_t a_rs, const float* rewards, int64_t r_rs,
+                         const float* next_states, int64_t n_rs, const float* dones, int64_t d_rs,
+                         void* stream);
+/* cql_trainer.py:94-111: both forwards, TD + penalty, backward -> grads, stats[0..2]. */
+int porl_qnet_cql_backward(porl_qnet* h, const porl_qnet_hyper* hp, void* stream);
+/* cql_trainer.py:112-113: Adam step. */
+int porl_qnet_apply(porl_qnet* h, const porl_qnet_hyper* hp, void* stream);
+int porl_qnet_learn(porl_qnet* h, const porl_qnet_hyper* hp, void* stream);   /* the two above */
+/* target_network.load_state_dict(q_network.state_dict()) */
+int porl_qnet_sync_target(porl_qnet* h, void* stream);
+/* q_network(states) (which=0) or target_network(states) (which=1) -> (batch, n_actions) */
+int porl_qnet_forward(porl_qnet* h, int which, const float* states, int64_t s_rs, int32_t batch,
+                      float* q_out, int64_t q_rs, void* stream);
+/* compute_cql_penalty(states, actions) -> out[0] (device float) */
+int porl_qnet_penalty(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions,
+                      int64_t a_rs, int32_t batch, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Building blocks, exported for tests, the replay buffer and other trainers
  * --------------------------------------------------------------------------------------------- */
 /* C = epilogue(op(A) * op(B)); mode 0 "NT": A (M,K), B (N,K); 1 "NN": A (M,K), B (K,N);

@@ -23,6 +23,10 @@ SYMBOLS = [
     "porl_iql_policy_apply", "porl_iql_step", "porl_iql_forward_value", "porl_iql_forward_policy",
     "porl_gemm_f32", "porl_adam_ema", "porl_gather_rows", "porl_sample_indices",
     "porl_prof_enable", "porl_prof_read", "porl_tune_set",
+    "porl_qnet_create", "porl_qnet_destroy", "porl_qnet_param_floats", "porl_qnet_tensors",
+    "porl_qnet_tensor_info", "porl_qnet_workspace_floats", "porl_qnet_bind", "porl_qnet_load_batch",
+    "porl_qnet_cql_backward", "porl_qnet_apply", "porl_qnet_learn", "porl_qnet_sync_target",
+    "porl_qnet_forward", "porl_qnet_penalty",
 ]
 
 
@@ -43,6 +47,20 @@ class IqlHyper(C.Structure):
                 ("value_step", C.c_int32), ("policy_step", C.c_int32), ("reserved", C.c_int32),
                 ("ema_beta", C.c_double), ("value_lr", C.c_double), ("policy_lr", C.c_double),
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
+
+
+class QnetCfg(C.Structure):
+    _fields_ = [("state_dim", C.c_int32), ("n_actions", C.c_int32), ("n_hidden", C.c_int32),
+                ("hidden", C.c_int32 * 8), ("max_batch", C.c_int32)]
+
+
+class QnetBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("params", "params_tgt", "grads", "adam_m", "adam_v", "workspace", "stats")]
+
+
+class QnetHyper(C.Structure):
+    _fields_ = [("gamma", C.c_float), ("alpha", C.c_float), ("inv_batch", C.c_float), ("step", C.c_int32),
+                ("lr", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
 
 
 class ProfEntry(C.Structure):
@@ -86,6 +104,23 @@ def _declare(lib):
     lib.porl_gather_rows.argtypes = [vp, i64, vp, i32, i32, vp, i64, vp]
     lib.porl_sample_indices.argtypes = [i64, i32, C.c_uint64, C.c_uint64, i64, vp, vp]
     lib.porl_tune_set.argtypes = [C.c_char_p, C.c_int]
+    lib.porl_qnet_create.argtypes = [C.POINTER(QnetCfg), C.POINTER(vp)]
+    lib.porl_qnet_destroy.argtypes = [vp]
+    lib.porl_qnet_destroy.restype = None
+    lib.porl_qnet_param_floats.argtypes = [vp]
+    lib.porl_qnet_param_floats.restype = i64
+    lib.porl_qnet_tensors.argtypes = [vp]
+    lib.porl_qnet_tensors.restype = i32
+    lib.porl_qnet_tensor_info.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
+    lib.porl_qnet_workspace_floats.argtypes = [vp]
+    lib.porl_qnet_workspace_floats.restype = i64
+    lib.porl_qnet_bind.argtypes = [vp, C.POINTER(QnetBuffers)]
+    lib.porl_qnet_load_batch.argtypes = [vp, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp]
+    for name in ("porl_qnet_cql_backward", "porl_qnet_apply", "porl_qnet_learn"):
+        getattr(lib, name).argtypes = [vp, C.POINTER(QnetHyper), vp]
+    lib.porl_qnet_sync_target.argtypes = [vp, vp]
+    lib.porl_qnet_forward.argtypes = [vp, C.c_int, vp, i64, i32, vp, i64, vp]
+    lib.porl_qnet_penalty.argtypes = [vp, vp, i64, vp, i64, i32, vp, vp]
     lib.porl_prof_enable.argtypes = [C.c_int]
     lib.porl_prof_read.argtypes = [C.POINTER(ProfEntry), C.c_int]
     for name in SYMBOLS:

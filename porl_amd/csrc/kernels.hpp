@@ -472,4 +472,97 @@ __global__ void sample_indices_kernel(int64_t n, int batch, uint64_t seed, uint6
   out[i] = base + feistel_index(n, i, seed, step, hb);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// CQL(H) on a plain-DQN TD loss for discrete actions  (src/porl/train/cql_trainer.py:60-124)
+//   y = r + gamma * max_a Q_tgt(s', a) * (1 - d);  td = mean((Q(s)[a] - y)^2)
+//   pen = mean(logsumexp_a Q(s, a) - ln A - Q(s)[a]);  loss = td + alpha * pen
+//   dL/dQ[b, j] = alpha/B * softmax_j + 1[j == a] * (2/B (Q[a] - y) - alpha/B)
+// One thread per row (A <= 64), per-block partial sums, fixed-order finalize.
+// ---------------------------------------------------------------------------------------------------
+struct CqlLossArgs {
+  const float* Q; const float* Qn; int ldq;
+  const int64_t* actions; const float* rew; const float* done;
+  float* dQ;                       // (B, ldq), padding columns zeroed
+  float* part_td; float* part_pen; // per block
+  int B, A;
+  float gamma, alpha, inv_batch, log_A;
+};
+
+__global__ __launch_bounds__(256) void cql_loss_kernel(const CqlLossArgs a) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  float td = 0.f, pen = 0.f;
+  if (b < a.B) {
+    const float* q = a.Q + (size_t)b * a.ldq;
+    const float* qn = a.Qn + (size_t)b * a.ldq;
+    float mx = -INFINITY, mxn = -INFINITY;
+    for (int j = 0; j < a.A; ++j) { mx = fmaxf(mx, q[j]); mxn = fmaxf(mxn, qn[j]); }
+    float se = 0.f;
+    for (int j = 0; j < a.A; ++j) se += expf(q[j] - mx);
+    const float lse = mx + logf(se);
+    const int act = (int)a.actions[b];
+    const float qa = q[act];
+    const float y = a.rew[b] + a.gamma * mxn * (1.f - a.done[b]);
+    const float diff = qa - y;
+    td = diff * diff;
+    pen = lse - a.log_A - qa;
+    float* dq = a.dQ + (size_t)b * a.ldq;
+    const float ab = a.alpha * a.inv_batch;
+    for (int j = 0; j < a.A; ++j) {
+      float g = ab * expf(q[j] - lse);
+      if (j == act) g += 2.f * a.inv_batch * diff - ab;
+      dq[j] = g;
+    }
+    for (int j = a.A; j < a.ldq; ++j) dq[j] = 0.f;
+  }
+  td = wave_sum(td); pen = wave_sum(pen);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[0][wave] = td; red[1][wave] = pen; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.part_td[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    a.part_pen[blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// stats[0] = loss, [1] = td, [2] = penalty (this rank's shares)
+__global__ __launch_bounds__(64) void cql_finalize_kernel(const float* __restrict__ part_td,
+                                                           const float* __restrict__ part_pen, int nblk,
+                                                           float inv_batch, float alpha, float* __restrict__ stats) {
+  float td = 0.f, pen = 0.f;
+  for (int k = threadIdx.x; k < nblk; k += 64) { td += part_td[k]; pen += part_pen[k]; }
+  td = wave_sum(td); pen = wave_sum(pen);
+  if (threadIdx.x == 0) {
+    td *= inv_batch; pen *= inv_batch;
+    stats[0] = td + alpha * pen; stats[1] = td; stats[2] = pen;
+  }
+}
+
+// penalty only (compute_cql_penalty, cql_trainer.py:60-86): per-block partials of lse - ln A - Q[a]
+__global__ __launch_bounds__(256) void cql_penalty_kernel(const float* __restrict__ Q, int ldq,
+                                                           const int64_t* __restrict__ actions, int B, int A,
+                                                           float log_A, float* __restrict__ part) {
+  __shared__ float red[4];
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  float pen = 0.f;
+  if (b < B) {
+    const float* q = Q + (size_t)b * ldq;
+    float mx = -INFINITY;
+    for (int j = 0; j < A; ++j) mx = fmaxf(mx, q[j]);
+    float se = 0.f;
+    for (int j = 0; j < A; ++j) se += expf(q[j] - mx);
+    pen = mx + logf(se) - log_A - q[(int)actions[b]];
+  }
+  pen = wave_sum(pen);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pen;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// int64 copy with stride (actions hand-over)
+__global__ void pack_i64_kernel(const int64_t* __restrict__ src, long stride, int n, int64_t* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[(long)i * stride];
+}
+
 }  // namespace porl

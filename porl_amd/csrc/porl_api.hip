@@ -851,3 +851,290 @@ int porl_prof_read(porl_prof_entry* out, int max_entries) {
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// Discrete-action CQL engine (QNetwork S -> hidden... -> A; src/porl/net/q_network.py:8-30)
+// =====================================================================================================
+struct porl_qnet {
+  porl_qnet_cfg cfg;
+  MlpLayout net;
+  int64_t n_params = 0;
+  std::vector<TensorInfo> tensors;
+  porl_qnet_buffers buf{};
+  bool bound = false;
+  int batch = 0;
+  int Sp = 0, Ap = 0, ld[PORL_MAX_HIDDEN + 2] = {0};     // padded leading dims per layer output
+  struct {
+    int64_t xs, xn, rew, done, actions;                  // actions: int64 stored in 2 floats each
+    int64_t act[PORL_MAX_HIDDEN + 1], tmp[2], dz[2], slab, part_td, part_pen, total;
+  } ws;
+};
+
+extern "C" {
+
+int porl_qnet_create(const porl_qnet_cfg* c, porl_qnet** out) {
+  if (!c || !out) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  if (c->state_dim < 1 || c->n_actions < 1 || c->max_batch < 1) PORL_FAIL(PORL_ERR_INVALID, "dimensions must be positive");
+  if (c->n_hidden < 1 || c->n_hidden > PORL_MAX_HIDDEN) PORL_FAIL(PORL_ERR_INVALID, "n_hidden must be in [1,%d]", PORL_MAX_HIDDEN);
+  if (c->n_actions > 64) PORL_FAIL(PORL_ERR_UNSUPPORTED, "n_actions > 64");
+  porl_qnet* h = new porl_qnet();
+  h->cfg = *c;
+  const int L = c->n_hidden, B = c->max_batch;
+  MlpLayout& m = h->net;
+  m.n_lin = L + 1;
+  m.dims[0] = c->state_dim;
+  for (int l = 0; l < L; ++l) {
+    if (c->hidden[l] < 1) { delete h; PORL_FAIL(PORL_ERR_INVALID, "hidden size must be positive"); }
+    m.dims[l + 1] = c->hidden[l];
+  }
+  m.dims[L + 1] = c->n_actions;
+  int64_t cur = 0;
+  for (int l = 0; l <= L; ++l) {
+    m.w[l] = add_tensor(h->tensors, cur, m.dims[l + 1], m.dims[l]);
+    m.b[l] = add_tensor(h->tensors, cur, 0, m.dims[l + 1]);
+  }
+  h->n_params = cur;
+  h->Sp = (int)ru4(c->state_dim);
+  h->Ap = (int)ru4(c->n_actions);
+  int maxld = h->Ap;
+  for (int l = 0; l <= L; ++l) { h->ld[l] = (int)ru4(m.dims[l + 1]); maxld = std::max(maxld, h->ld[l]); }
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += ru4(n); return r; };
+  h->ws.xs = take((int64_t)B * h->Sp); h->ws.xn = take((int64_t)B * h->Sp);
+  h->ws.rew = take(B); h->ws.done = take(B); h->ws.actions = take(2 * (int64_t)B);
+  for (int l = 0; l <= L; ++l) h->ws.act[l] = take((int64_t)B * h->ld[l]);
+  h->ws.tmp[0] = take((int64_t)B * maxld); h->ws.tmp[1] = take((int64_t)B * maxld);
+  h->ws.dz[0] = take((int64_t)B * maxld); h->ws.dz[1] = take((int64_t)B * maxld);
+  h->ws.slab = take((int64_t)SK_MAX * (cur + 64));
+  const int nblk = cdiv(B, 256);
+  h->ws.part_td = take(nblk); h->ws.part_pen = take(nblk);
+  h->ws.total = o;
+  *out = h;
+  return PORL_OK;
+}
+
+void porl_qnet_destroy(porl_qnet* h) { delete h; }
+int64_t porl_qnet_param_floats(const porl_qnet* h) { return h ? h->n_params : 0; }
+int32_t porl_qnet_tensors(const porl_qnet* h) { return h ? (int32_t)h->tensors.size() : 0; }
+int porl_qnet_tensor_info(const porl_qnet* h, int index, int64_t* offset, int32_t* rows, int32_t* cols) {
+  if (!h || index < 0 || index >= (int)h->tensors.size()) PORL_FAIL(PORL_ERR_INVALID, "tensor index out of range");
+  if (offset) *offset = h->tensors[index].off;
+  if (rows) *rows = h->tensors[index].rows;
+  if (cols) *cols = h->tensors[index].cols;
+  return PORL_OK;
+}
+int64_t porl_qnet_workspace_floats(const porl_qnet* h) { return h ? h->ws.total : 0; }
+
+int porl_qnet_bind(porl_qnet* h, const porl_qnet_buffers* b) {
+  if (!h || !b) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  const void* ptrs[] = {b->params, b->params_tgt, b->grads, b->adam_m, b->adam_v, b->workspace, b->stats};
+  for (const void* p : ptrs) {
+    if (!p) PORL_FAIL(PORL_ERR_INVALID, "null buffer");
+    if (!aligned16(p)) PORL_FAIL(PORL_ERR_INVALID, "buffers must be 16-byte aligned");
+  }
+  h->buf = *b;
+  h->bound = true;
+  h->batch = 0;
+  return PORL_OK;
+}
+
+static int qnet_ready(const porl_qnet* h, bool need_batch) {
+  if (!h) PORL_FAIL(PORL_ERR_INVALID, "null engine");
+  if (!h->bound) PORL_FAIL(PORL_ERR_UNBOUND, "porl_qnet_bind() has not been called");
+  if (need_batch && h->batch <= 0) PORL_FAIL(PORL_ERR_INVALID, "no minibatch loaded (porl_qnet_load_batch)");
+  return 0;
+}
+
+int porl_qnet_load_batch(porl_qnet* h, int32_t batch, const float* states, int64_t s_rs, const int64_t* actions,
+                         int64_t a_rs, const float* rewards, int64_t r_rs, const float* next_states, int64_t n_rs,
+                         const float* dones, int64_t d_rs, void* stream) {
+  PORL_TRY(qnet_ready(h, false));
+  if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
+  if (!states) PORL_FAIL(PORL_ERR_INVALID, "null states");
+  float* W = h->buf.workspace;
+  hipStream_t s = (hipStream_t)stream;
+  PackArgs a{};
+  a.rows = batch;
+  auto job = [&](const float* src, int64_t rs, float* dst, int cols, int ld) {
+    PackJob& j = a.job[a.njobs++];
+    j.src = src; j.dst = dst; j.src_row_stride = rs; j.src_col_stride = 1; j.cols = cols; j.ld = ld;
+  };
+  job(states, s_rs, W + h->ws.xs, h->cfg.state_dim, h->Sp);
+  if (next_states) job(next_states, n_rs, W + h->ws.xn, h->cfg.state_dim, h->Sp);
+  if (rewards) job(rewards, r_rs, W + h->ws.rew, 1, 1);
+  if (dones) job(dones, d_rs, W + h->ws.done, 1, 1);
+  const long n = (long)batch * h->Sp;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024), a.njobs), dim3(256), 0, s, a);
+  PORL_HIP(hipGetLastError());
+  if (actions) {
+    hipLaunchKernelGGL(pack_i64_kernel, dim3(cdiv(batch, 256)), dim3(256), 0, s, actions, (long)a_rs, batch,
+                       reinterpret_cast<int64_t*>(W + h->ws.actions));
+    PORL_HIP(hipGetLastError());
+  }
+  h->batch = batch;
+  return PORL_OK;
+}
+
+// forward of `nnets` parameter sets; set k reads input in_k and writes hidden activations to dst_k[l]
+static int qnet_forward(porl_qnet* h, int nnets, const float* const* params, const float* const* inputs,
+                        float* const (*dst)[PORL_MAX_HIDDEN + 1], int B, hipStream_t s) {
+  const int L = h->cfg.n_hidden;
+  for (int l = 0; l <= L; ++l) {
+    GemmGroup g{};
+    g.nprob = nnets;
+    const int K = h->net.dims[l], Nn = h->net.dims[l + 1];
+    for (int k = 0; k < nnets; ++k) {
+      const float* in = l == 0 ? inputs[k] : dst[k][l - 1];
+      const int ldin = l == 0 ? h->Sp : h->ld[l - 1];
+      GemmProb p = make_prob(GEMM_NT, in, ldin, params[k] + h->net.w[l], K, dst[k][l], h->ld[l], B, Nn, K);
+      p.bias = params[k] + h->net.b[l];
+      p.act = l < L ? ACT_RELU : ACT_NONE;
+      g.p[k] = p;
+    }
+    PORL_TRY(launch_group(g, pick_tile(g), s));
+  }
+  return PORL_OK;
+}
+
+int porl_qnet_cql_backward(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
+  PORL_TRY(qnet_ready(h, true));
+  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+  hipStream_t s = (hipStream_t)stream;
+  const int B = h->batch, L = h->cfg.n_hidden, A = h->cfg.n_actions;
+  float* W = h->buf.workspace;
+  // forward: target net on s' (activations ping-pong in tmp), online net on s (activations kept)
+  float* dst[2][PORL_MAX_HIDDEN + 1];
+  for (int l = 0; l <= L; ++l) { dst[0][l] = W + h->ws.tmp[l & 1]; dst[1][l] = W + h->ws.act[l]; }
+  const float* params[2] = {h->buf.params_tgt, h->buf.params};
+  const float* inputs[2] = {W + h->ws.xn, W + h->ws.xs};
+  PORL_TRY(qnet_forward(h, 2, params, inputs, dst, B, s));
+  float* Qn = dst[0][L];
+  float* Q = dst[1][L];
+  float* dz = W + h->ws.dz[L & 1];
+  const int nblk = cdiv(B, 256);
+  {
+    CqlLossArgs a{};
+    a.Q = Q; a.Qn = Qn; a.ldq = h->ld[L];
+    a.actions = reinterpret_cast<const int64_t*>(W + h->ws.actions); a.rew = W + h->ws.rew; a.done = W + h->ws.done;
+    a.dQ = dz; a.part_td = W + h->ws.part_td; a.part_pen = W + h->ws.part_pen;
+    a.B = B; a.A = A; a.gamma = hp->gamma; a.alpha = hp->alpha; a.inv_batch = hp->inv_batch;
+    a.log_A = (float)std::log((double)A);
+    hipLaunchKernelGGL(cql_loss_kernel, dim3(nblk), dim3(256), 0, s, a);
+    PORL_HIP(hipGetLastError());
+    hipLaunchKernelGGL(cql_finalize_kernel, dim3(1), dim3(64), 0, s, W + h->ws.part_td, W + h->ws.part_pen, nblk,
+                       hp->inv_batch, hp->alpha, h->buf.stats);
+    PORL_HIP(hipGetLastError());
+  }
+  // backward, top down: dW_l = dZ_l^T In_l (split over the batch), dZ_{l-1} = (dZ_l W_l) . 1[In_l > 0]
+  float* G = h->buf.grads;
+  ReduceArgs red{};
+  float* slab = W + h->ws.slab;
+  for (int l = L; l >= 0; --l) {
+    const int out_d = h->net.dims[l + 1], in_d = h->net.dims[l];
+    const float* in = l == 0 ? W + h->ws.xs : W + h->ws.act[l - 1];
+    const int ldin = l == 0 ? h->Sp : h->ld[l - 1];
+    GemmGroup g{};
+    g.p[g.nprob] = make_prob(GEMM_TN, dz, h->ld[l], in, ldin, G + h->net.w[l], in_d, out_d, in_d, B);
+    g.p[g.nprob].colsum = G + h->net.b[l];
+    GemmProb& wg = g.p[g.nprob++];
+    float* dz_next = nullptr;
+    if (l > 0) {
+      dz_next = W + h->ws.dz[(l - 1) & 1];
+      GemmProb q = make_prob(GEMM_NN, dz, h->ld[l], h->buf.params + h->net.w[l], in_d, dz_next, h->ld[l - 1], B, in_d, out_d);
+      q.mask = in; q.ldmask = ldin;
+      g.p[g.nprob++] = q;
+    }
+    const int tile = TILE_64x64;
+    const int sk = pick_splitk(out_d, in_d, B, 1, 64, 64);
+    if (sk > 1) {
+      const int64_t per = (int64_t)out_d * in_d;
+      if (red.njobs + 2 > 8) { PORL_TRY(launch_reduce(red, s)); red = ReduceArgs{}; }
+      float* slabW = slab; slab += (int64_t)sk * per;
+      float* slabC = slab; slab += (int64_t)sk * out_d;
+      wg.splitk = sk; wg.C = slabW; wg.colsum = slabC;
+      add_reduce(red, G + h->net.w[l], slabW, per, per, sk);
+      add_reduce(red, G + h->net.b[l], slabC, out_d, out_d, sk);
+    }
+    PORL_TRY(launch_group(g, tile, s));
+    if (red.njobs == 8 || l == 0) { PORL_TRY(launch_reduce(red, s)); red = ReduceArgs{}; }
+    dz = dz_next;
+  }
+  return PORL_OK;
+}
+
+int porl_qnet_apply(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
+  PORL_TRY(qnet_ready(h, false));
+  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+  return adam_launch(h->buf.params, h->buf.grads, h->buf.adam_m, h->buf.adam_v, nullptr, h->n_params, hp->lr, hp->step,
+                     hp->adam_beta1, hp->adam_beta2, hp->adam_eps, 0.0, (hipStream_t)stream);
+}
+
+int porl_qnet_learn(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
+  PORL_TRY(porl_qnet_cql_backward(h, hp, stream));
+  return porl_qnet_apply(h, hp, stream);
+}
+
+int porl_qnet_sync_target(porl_qnet* h, void* stream) {
+  PORL_TRY(qnet_ready(h, false));
+  PORL_HIP(hipMemcpyAsync(h->buf.params_tgt, h->buf.params, sizeof(float) * h->n_params, hipMemcpyDeviceToDevice,
+                          (hipStream_t)stream));
+  return PORL_OK;
+}
+
+// Q(s, .) for a loaded batch of states (which = 0 online, 1 target) -> q_out (batch, n_actions), row stride q_rs
+int porl_qnet_forward(porl_qnet* h, int which, const float* states, int64_t s_rs, int32_t batch, float* q_out,
+                      int64_t q_rs, void* stream) {
+  PORL_TRY(qnet_ready(h, false));
+  if (!q_out) PORL_FAIL(PORL_ERR_INVALID, "null output");
+  hipStream_t s = (hipStream_t)stream;
+  PORL_TRY(porl_qnet_load_batch(h, batch, states, s_rs, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, stream));
+  h->batch = 0;
+  const int L = h->cfg.n_hidden;
+  float* W = h->buf.workspace;
+  float* dst[1][PORL_MAX_HIDDEN + 1];
+  for (int l = 0; l <= L; ++l) dst[0][l] = W + h->ws.tmp[l & 1];
+  const float* params[1] = {which ? h->buf.params_tgt : h->buf.params};
+  const float* inputs[1] = {W + h->ws.xs};
+  PORL_TRY(qnet_forward(h, 1, params, inputs, dst, batch, s));
+  PackArgs a{};
+  a.rows = batch; a.njobs = 1;
+  a.job[0].src = dst[0][L]; a.job[0].dst = q_out; a.job[0].src_row_stride = h->ld[L]; a.job[0].src_col_stride = 1;
+  a.job[0].cols = h->cfg.n_actions; a.job[0].ld = (int)q_rs;
+  if (q_rs < h->cfg.n_actions) PORL_FAIL(PORL_ERR_INVALID, "q_rs smaller than n_actions");
+  const long n = (long)batch * q_rs;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024), 1), dim3(256), 0, s, a);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+// mean_b( logsumexp_a Q(s_b, a) - ln A - Q(s_b, a_b) ) -> out[0]   (compute_cql_penalty)
+int porl_qnet_penalty(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions, int64_t a_rs,
+                      int32_t batch, float* out, void* stream) {
+  PORL_TRY(qnet_ready(h, false));
+  if (!out || !actions) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  PORL_TRY(porl_qnet_load_batch(h, batch, states, s_rs, actions, a_rs, nullptr, 0, nullptr, 0, nullptr, 0, stream));
+  h->batch = 0;
+  const int L = h->cfg.n_hidden;
+  float* W = h->buf.workspace;
+  float* dst[1][PORL_MAX_HIDDEN + 1];
+  for (int l = 0; l <= L; ++l) dst[0][l] = W + h->ws.tmp[l & 1];
+  const float* params[1] = {h->buf.params};
+  const float* inputs[1] = {W + h->ws.xs};
+  PORL_TRY(qnet_forward(h, 1, params, inputs, dst, batch, s));
+  const int nblk = cdiv(batch, 256);
+  hipLaunchKernelGGL(cql_penalty_kernel, dim3(nblk), dim3(256), 0, s, dst[0][L], h->ld[L],
+                     reinterpret_cast<const int64_t*>(W + h->ws.actions), batch, h->cfg.n_actions,
+                     (float)std::log((double)h->cfg.n_actions), W + h->ws.part_pen);
+  PORL_HIP(hipGetLastError());
+  ReduceArgs r{};
+  // sum of the per-block partials, scaled by 1/B: reuse the finalize kernel (td part = 0)
+  hipLaunchKernelGGL(cql_finalize_kernel, dim3(1), dim3(64), 0, s, W + h->ws.part_pen, W + h->ws.part_pen, nblk,
+                     1.0f / batch, 0.0f, W + h->ws.part_td);
+  PORL_HIP(hipGetLastError());
+  PORL_HIP(hipMemcpyAsync(out, W + h->ws.part_td + 2, sizeof(float), hipMemcpyDeviceToDevice, s));
+  (void)r;
+  return PORL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,237 @@
+"""CQL trainer — drop-in for the hot path of /root/reference/src/porl/train/cql_trainer.py (+ the pieces of
+dqn_trainer.py it inherits): `learn()`, `compute_cql_penalty`, `train_offline`, `get_action`,
+`select_action`, with `q_network`, `target_network`, `optimizer`, `replay_buffer`, `batch_size`, `gamma`,
+`alpha`, `action_size`, `device` attributes.
+
+The reference's constructor is broken upstream (it forwards 10 positionals to an 11-positional base,
+SURVEY.md §2.1); this one accepts the keyword call of scripts/train_cql.py:18-29 and behaves as evidently
+intended (`learning_rate` defaults to the hard-coded 5e-4 of dqn_trainer.py:71).
+
+`learn()` = sample (host index stream identical to the reference under the same numpy seed, gather on the
+device) + one fused device update: target forward, online forward, TD + CQL(H) penalty, backward, Adam —
+hand-written gfx950 kernels behind `porl_qnet_*` (include/porl_hip.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _native as N
+from ..buffer.replay_buffer import ReplayBuffer
+from ..engine import _norm_device
+from ..net.q_network import QNetwork
+from ..parallel import GradExchange
+from ..utils.logger import Logger
+
+
+class QnetEngine:
+    def __init__(self, state_dim, n_actions, hidden, max_batch, device):
+        self.device = _norm_device(device)
+        hid = (C.c_int32 * 8)(*hidden)
+        self.cfg = N.QnetCfg(int(state_dim), int(n_actions), len(hidden), hid, int(max_batch))
+        self._lib = N.lib()
+        h = C.c_void_p()
+        N.check(self._lib.porl_qnet_create(C.byref(self.cfg), C.byref(h)), "porl_qnet_create")
+        self._h = h
+        self.n_params = int(self._lib.porl_qnet_param_floats(h))
+        z = lambda: torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        self.params, self.params_tgt, self.grads, self.adam_m, self.adam_v = z(), z(), z(), z(), z()
+        self.stats = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.workspace, self._bound = None, False
+
+    def tensor_table(self):
+        out = []
+        off, r, c = C.c_int64(), C.c_int32(), C.c_int32()
+        for i in range(int(self._lib.porl_qnet_tensors(self._h))):
+            N.check(self._lib.porl_qnet_tensor_info(self._h, i, C.byref(off), C.byref(r), C.byref(c)))
+            out.append((off.value, (c.value,) if r.value == 0 else (r.value, c.value)))
+        return out
+
+    def views(self, flat):
+        return [flat[o:o + math.prod(s)].view(s) for o, s in self.tensor_table()]
+
+    def _ensure_bound(self):
+        if self.device.type != "cuda":
+            raise N.NativeError("porl_amd computes on a HIP device only (device='cuda'); there is no CPU path")
+        if self._bound:
+            return
+        self.workspace = torch.empty(int(self._lib.porl_qnet_workspace_floats(self._h)), dtype=torch.float32,
+                                     device=self.device)
+        b = N.QnetBuffers(*[C.c_void_p(t.data_ptr()) for t in (self.params, self.params_tgt, self.grads,
+                                                                 self.adam_m, self.adam_v, self.workspace, self.stats)])
+        N.check(self._lib.porl_qnet_bind(self._h, C.byref(b)), "porl_qnet_bind")
+        self._bound = True
+
+    def _states(self, x, what="states"):
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.reshape(x.shape[0], -1)
+        if x.shape[1] != self.cfg.state_dim:
+            raise RuntimeError(f"{what}: expected (B, {self.cfg.state_dim}), got {tuple(x.shape)}")
+        if x.device != self.device:
+            raise RuntimeError(f"{what} on {x.device}, engine on {self.device}")
+        return x if x.stride(1) == 1 else x.contiguous()
+
+    def load_batch(self, states, actions, rewards, next_states, dones):
+        self._ensure_bound()
+        states, next_states = self._states(states), self._states(next_states, "next_states")
+        B = states.shape[0]
+        if B > self.cfg.max_batch:
+            raise RuntimeError(f"batch {B} exceeds engine max_batch {self.cfg.max_batch}")
+        if actions.dtype != torch.int64:
+            actions = actions.long()
+        rewards, dones = rewards.float(), dones.float()
+        self._held = (states, actions, rewards, next_states, dones)
+        N.check(self._lib.porl_qnet_load_batch(self._h, B, N.ptr(states), states.stride(0), N.ptr(actions),
+                                               actions.stride(0), N.ptr(rewards), rewards.stride(0),
+                                               N.ptr(next_states), next_states.stride(0), N.ptr(dones),
+                                               dones.stride(0), N.current_stream_ptr()), "porl_qnet_load_batch")
+        return B
+
+    def hyper(self, gamma, alpha, inv_batch, step, lr, betas=(0.9, 0.999), eps=1e-8):
+        return N.QnetHyper(gamma, alpha, inv_batch, step, lr, betas[0], betas[1], eps)
+
+    def cql_backward(self, hp): N.check(self._lib.porl_qnet_cql_backward(self._h, C.byref(hp), N.current_stream_ptr()), "porl_qnet_cql_backward")
+    def apply(self, hp): N.check(self._lib.porl_qnet_apply(self._h, C.byref(hp), N.current_stream_ptr()), "porl_qnet_apply")
+    def learn(self, hp): N.check(self._lib.porl_qnet_learn(self._h, C.byref(hp), N.current_stream_ptr()), "porl_qnet_learn")
+
+    def sync_target(self):
+        self._ensure_bound()
+        N.check(self._lib.porl_qnet_sync_target(self._h, N.current_stream_ptr()), "porl_qnet_sync_target")
+
+    def forward(self, x, which=0):
+        self._ensure_bound()
+        x = self._states(x)
+        q = torch.empty(x.shape[0], self.cfg.n_actions, dtype=torch.float32, device=self.device)
+        N.check(self._lib.porl_qnet_forward(self._h, which, N.ptr(x), x.stride(0), x.shape[0], N.ptr(q),
+                                            self.cfg.n_actions, N.current_stream_ptr()), "porl_qnet_forward")
+        return q
+
+    def penalty(self, states, actions):
+        self._ensure_bound()
+        states = self._states(states)
+        actions = actions.long()
+        out = torch.empty(1, dtype=torch.float32, device=self.device)
+        N.check(self._lib.porl_qnet_penalty(self._h, N.ptr(states), states.stride(0), N.ptr(actions),
+                                            actions.stride(0), states.shape[0], N.ptr(out),
+                                            N.current_stream_ptr()), "porl_qnet_penalty")
+        return out[0]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.porl_qnet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class _FlatAdam:
+    """torch.optim.Adam-format state over the engine's flat group (see agent/_iql.py:ArenaAdam)."""
+
+    def __init__(self, engine, params, lr):
+        self._eng, self._params, self.step_count = engine, params, 0
+        self.param_groups = [dict(lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, params=params)]
+
+    def zero_grad(self, set_to_none=True):
+        pass
+
+    def state_dict(self):
+        ms, vs = self._eng.views(self._eng.adam_m), self._eng.views(self._eng.adam_v)
+        state = {i: dict(step=torch.tensor(float(self.step_count)), exp_avg=m.clone(), exp_avg_sq=v.clone())
+                 for i, (m, v) in enumerate(zip(ms, vs))} if self.step_count else {}
+        g = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        g["params"] = list(range(len(self._params)))
+        return dict(state=state, param_groups=[g])
+
+
+class CQLTrainer:
+    def __init__(self, state_size, action_size, gamma, epsilon=1.0, epsilon_min=0.05, epsilon_decay=0.99,
+                 update_target_freq=10, device=torch.device("cpu"), network=QNetwork, log_dir="logs",
+                 num_epochs=1000, threshold=0.1, alpha=1, learning_rate=0.0005, replay_buffer=None,
+                 batch_size=64, max_batch=4096):
+        self.state_size, self.action_size = state_size, action_size
+        self.device = torch.device(device)
+        self.gamma, self.epsilon, self.epsilon_min, self.epsilon_decay = gamma, epsilon, epsilon_min, epsilon_decay
+        self.learning_rate, self.update_target_freq = learning_rate, update_target_freq
+        self.num_epochs, self.threshold, self.alpha = num_epochs, threshold, alpha
+        if network is not QNetwork:
+            raise NotImplementedError("only QNetwork is on the accelerated path")
+        # same construction order / RNG consumption as dqn_trainer.py:66-70
+        self.q_network = network(state_size, action_size)
+        self.target_network = network(state_size, action_size)
+        hidden = self.q_network._spec[2]
+        self._engine = QnetEngine(state_size, action_size, hidden, max(max_batch, batch_size), self.device)
+        with torch.no_grad():
+            for mod, flat, which in ((self.q_network, self._engine.params, 0),
+                                     (self.target_network, self._engine.params_tgt, 1)):
+                for p, v in zip(mod.parameters(), self._engine.views(flat)):
+                    v.copy_(p)
+                    p.data = v
+                mod._engine, mod._which = self._engine, which
+            self._engine.params_tgt.copy_(self._engine.params)       # target.load_state_dict(q.state_dict())
+        self.target_network.eval()
+        self.optimizer = _FlatAdam(self._engine, list(self.q_network.parameters()), learning_rate)
+        self.replay_buffer = replay_buffer if replay_buffer is not None else ReplayBuffer(100000, (state_size,), self.device)
+        self.batch_size = batch_size
+        self.logger = Logger(log_dir=log_dir)
+        self.logger.log_hyperparameters(dict(learning_rate=learning_rate, gamma=gamma, batch_size=batch_size,
+                                             epsilon_decay=epsilon_decay, update_target_freq=update_target_freq))
+        self.training_step = 0
+        self._exchange = GradExchange()
+        self.async_losses = False
+
+    # -- hot path ---------------------------------------------------------------------------------
+    def learn_on(self, states, actions, rewards, next_states, dones):
+        """cql_trainer.py:94-124 on an explicit minibatch (device tensors)."""
+        eng, ex = self._engine, self._exchange
+        B = eng.load_batch(states, actions, rewards, next_states, dones)
+        self.optimizer.step_count += 1
+        g = self.optimizer.param_groups[0]
+        hp = eng.hyper(self.gamma, float(self.alpha), 1.0 / (B * ex.world_size), self.optimizer.step_count,
+                       g["lr"], g["betas"], g["eps"])
+        if ex.world_size == 1:
+            eng.learn(hp)
+        else:
+            eng.cql_backward(hp)
+            ex.allreduce_sum_(eng.grads)
+            ex.allreduce_sum_(eng.stats[:3])
+            eng.apply(hp)
+        if self.async_losses:
+            return eng.stats[:3]
+        loss, self.last_td_loss, self.last_cql_penalty = eng.stats[:3].tolist()
+        return loss
+
+    def learn(self):
+        return self.learn_on(*self.replay_buffer.sample(self.batch_size))
+
+    def compute_cql_penalty(self, states, actions):
+        return self._engine.penalty(states, actions)
+
+    def sync_target(self):
+        self._engine.sync_target()
+
+    def train_offline(self, policy=None, num_iterations: int = 10000):
+        losses = []
+        for self.training_step in range(num_iterations):
+            loss = self.learn() if policy is None else policy()
+            self.logger.log_loss(self.training_step, loss)
+            if self.training_step % self.update_target_freq == 0:      # dqn_trainer.py:195-196
+                self.sync_target()
+            losses.append(loss)
+        self.logger.close()
+        return losses
+
+    # -- acting -----------------------------------------------------------------------------------
+    def get_action(self, state: np.ndarray) -> int:
+        x = torch.as_tensor(np.asarray(state), dtype=torch.float32, device=self.device).unsqueeze(0)
+        return int(self.q_network(x).argmax(dim=1).item())
+
+    def select_action(self, state: np.ndarray) -> int:
+        if np.random.rand() < self.epsilon:
+            return int(np.random.randint(self.action_size))
+        return self.get_action(state)

@@ -1,0 +1,99 @@
+"""CQL device step (through CQLTrainer and the C ABI) against the reference's goldens and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from oracle.por_oracle import CqlOracle
+from porl_amd.util.synth import make_discrete_transitions
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+def _trainer(S, A, B, seed, **kw):
+    from porl_amd.train.cql_trainer import CQLTrainer
+    torch.manual_seed(seed)
+    return CQLTrainer(state_size=S, action_size=A, gamma=kw.pop("gamma", 0.99), device=DEV, batch_size=B, **kw)
+
+
+def _np_sd(mod):
+    return {k: v.detach().cpu().numpy() for k, v in mod.state_dict().items()}
+
+
+@pytest.mark.parametrize("name", ["cql_s60_a10_b64", "cql_s8_a4_b256"])
+def test_cql_learn_matches_reference_golden(name):
+    z, meta = load_golden(name)
+    S, A, B, K, N = (int(meta[k]) for k in ("S", "A", "B", "K", "N"))
+    t = _trainer(S, A, B, int(meta["seed_model"]), alpha=meta["alpha"])
+    for k, v in sub(z, "init/").items():
+        assert np.array_equal(_np_sd(t.q_network)[k], v), k
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=int(meta["seed_data"]))
+    for i in range(N):
+        t.replay_buffer.push(st[i], int(ac[i]), float(rw[i]), ns[i], bool(dn[i]))
+    np.random.seed(int(meta["seed_np"]))                      # the reference's index stream
+    for k in range(K):
+        loss = t.learn()
+        np.testing.assert_allclose(loss, z["loss"][k], rtol=1e-5)
+        if (k + 1) % int(meta["sync_every"]) == 0:
+            t.sync_target()
+    for k, v in sub(z, "final/").items():
+        np.testing.assert_allclose(_np_sd(t.q_network)[k], v, atol=1e-5, err_msg=k)
+    for k, v in sub(z, "final_target/").items():
+        np.testing.assert_allclose(_np_sd(t.target_network)[k], v, atol=1e-5, err_msg=k)
+    idx = z["indices"][0]
+    pen = t.compute_cql_penalty(torch.from_numpy(st[idx]).to(DEV), torch.from_numpy(ac[idx]).to(DEV))
+    np.testing.assert_allclose(float(pen), float(z["penalty_final_on_batch0"]), atol=2e-6)
+    am = sub(z, "adam/")
+    sd = t.optimizer.state_dict()
+    names = [n for n, _ in t.q_network.named_parameters()]
+    for i, n in enumerate(names):
+        np.testing.assert_allclose(sd["state"][i]["exp_avg"].cpu().numpy(), am[n + ".exp_avg"], atol=1e-7, rtol=1e-4)
+
+
+def test_cql_config3_vs_oracle():
+    """BASELINE config 3 shapes: S=60, A=10, B=4096, Q-net 64-128-64."""
+    S, A, B, N = 60, 10, 4096, 20000
+    t = _trainer(S, A, B, 0)
+    o = CqlOracle(_np_sd(t.q_network), A, lr=5e-4)
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=9)
+    rng = np.random.default_rng(0)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    for k in range(4):
+        idx = rng.choice(N, B, replace=False)
+        loss = t.learn_on(dev(st[idx]), dev(ac[idx]), dev(rw[idx]), dev(ns[idx]), dev(dn[idx]))
+        np.testing.assert_allclose(loss, o.learn(st[idx], ac[idx], rw[idx], ns[idx], dn[idx]), rtol=1e-5)
+        if k == 1:
+            t.sync_target(); o.sync_target()
+    for k, v in o.Q.items():
+        np.testing.assert_allclose(_np_sd(t.q_network)[k], v, atol=1e-5, err_msg=k)
+    x = dev(st[:33])
+    q_ref = o.Q
+    from oracle.por_oracle import qnet_forward
+    np.testing.assert_allclose(t.q_network(x).cpu().numpy(), qnet_forward(o.Q, "", st[:33], 4)[0], atol=2e-6)
+    np.testing.assert_allclose(t.target_network(x).cpu().numpy(), qnet_forward(o.T, "", st[:33], 4)[0], atol=2e-6)
+    assert t.get_action(st[0]) == int(np.argmax(qnet_forward(o.Q, "", st[:1], 4)[0]))
+
+
+def test_replay_buffer_sample_matches_reference_stream():
+    """Drop-in ReplayBuffer: ring semantics, numpy index stream and dtypes of the reference (golden)."""
+    from porl_amd.buffer.replay_buffer import ReplayBuffer
+    z, meta = load_golden("replay_ring")
+    N, cap, S, B, K = (int(meta[k]) for k in ("N", "cap", "S", "B", "K"))
+    rb = ReplayBuffer(cap, (S,), DEV)
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, 4, seed=5)
+    for i in range(N):
+        rb.push(st[i], int(ac[i]), float(rw[i]), ns[i], bool(dn[i]))
+    assert len(rb) == int(z["size"]) and rb.position == int(z["position"])
+    np.random.seed(int(meta["seed_np"]))
+    for k in range(K):
+        s, a, r, n, d = rb.sample(B)
+        assert [str(t.dtype) for t in (s, a, r, n, d)] == [str(x) for x in z["dtype_names"]]
+        for got, key in ((s, "s"), (a, "a"), (r, "r"), (n, "n"), (d, "d")):
+            assert np.array_equal(got.cpu().numpy(), z[f"{key}{k}"]), key
+    with pytest.raises(ValueError):
+        rb.sample(len(rb) + 1)
+    # pushes after the mirror exists are reflected
+    rb.push(st[0] + 1, 3, 2.5, ns[0], True)
+    s, a, r, n, d = rb.sample_at(np.array([(rb.position - 1) % cap]))
+    assert np.array_equal(s.cpu().numpy()[0], st[0] + 1) and int(a) == 3 and float(r) == 2.5 and float(d) == 1.0
