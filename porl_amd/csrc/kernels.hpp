@@ -473,6 +473,150 @@ __global__ void sample_indices_kernel(int64_t n, int batch, uint64_t seed, uint6
 }
 
 // ---------------------------------------------------------------------------------------------------
+// LayerNorm (+ReLU) between a hidden Linear and its activation (util/util.py:36-37; nn.LayerNorm(H): biased
+// variance, eps 1e-5 inside the sqrt, affine).  One block per row group; a block walks its rows one at a
+// time, 256 threads striding over the H columns (H <= 256 * LN_MAX_COLS).
+//   forward : Z (B, ld) -> H = relu(xhat * gamma + beta) written in place of Z; optionally keeps xhat and
+//             rstd for the backward pass and accumulates the fused scalar head v[b] = sum_j H[b,j] w[j]
+//   backward: dZ = (dxh - mean(dxh) - xhat * mean(dxh * xhat)) * rstd, dxh = dy * gamma, dy = dH . 1[H > 0]
+//             with dH either read from memory or made on the fly as dv[b] * w[j] (top layer); per-block
+//             partial column sums of dgamma = dy * xhat, dbeta = dy and (top layer) dw = dv * H
+// ---------------------------------------------------------------------------------------------------
+constexpr int LN_MAX_COLS = 8;
+constexpr float LN_EPS = 1e-5f;
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();                         // sh may still be read from the previous use
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+struct LnFwdArgs {
+  float* Z[4]; float* xhat[4]; float* rstd[4];        // per net; xhat/rstd may be null (no backward)
+  const float* gamma[4]; const float* beta[4];
+  const float* headw[4]; const float* headb[4]; float* headout[4];   // fused head (may be null)
+  int nnets, B, H, ld, rows_per_block;
+};
+
+__global__ __launch_bounds__(256) void ln_relu_fwd_kernel(const LnFwdArgs a) {
+  __shared__ float sh[4];
+  const int net = blockIdx.y;
+  float* __restrict__ Z = a.Z[net];
+  const float* __restrict__ g = a.gamma[net];
+  const float* __restrict__ be = a.beta[net];
+  const int row0 = blockIdx.x * a.rows_per_block, row1 = min(a.B, row0 + a.rows_per_block);
+  const float invH = 1.f / (float)a.H;
+  for (int b = row0; b < row1; ++b) {
+    float z[LN_MAX_COLS];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_COLS; ++c) {
+      const int j = threadIdx.x + 256 * c;
+      z[c] = j < a.H ? Z[(size_t)b * a.ld + j] : 0.f;
+      s += z[c];
+    }
+    const float mu = block_sum_256(s, sh) * invH;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_COLS; ++c) {
+      const int j = threadIdx.x + 256 * c;
+      const float d = j < a.H ? z[c] - mu : 0.f;
+      q += d * d;
+    }
+    const float var = block_sum_256(q, sh) * invH;
+    const float rs = 1.f / sqrtf(var + LN_EPS);
+    float hv = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_COLS; ++c) {
+      const int j = threadIdx.x + 256 * c;
+      if (j < a.H) {
+        const float xh = (z[c] - mu) * rs;
+        const float h = fmaxf(xh * g[j] + be[j], 0.f);
+        Z[(size_t)b * a.ld + j] = h;
+        if (a.xhat[net]) a.xhat[net][(size_t)b * a.ld + j] = xh;
+        if (a.headw[net]) hv += h * a.headw[net][j];
+      }
+    }
+    if (a.rstd[net] && threadIdx.x == 0) a.rstd[net][b] = rs;
+    if (a.headw[net]) {
+      const float v = block_sum_256(hv, sh);
+      if (threadIdx.x == 0) a.headout[net][b] = v + (a.headb[net] ? a.headb[net][0] : 0.f);
+    }
+  }
+}
+
+struct LnBwdArgs {
+  const float* dH[2];            // (B, ld) upstream gradient, or null -> dv[b] * headw[j]
+  const float* dv[2]; const float* headw[2];
+  const float* Hact[2]; const float* xhat[2]; const float* rstd[2]; const float* gamma[2];
+  float* dZ[2];                  // (B, ld)
+  float* part_dgamma[2]; float* part_dbeta[2]; float* part_dhead[2];   // [nblk][H]; dhead only for the top layer
+  int nnets, B, H, ld, rows_per_block;
+};
+
+__global__ __launch_bounds__(256) void ln_relu_bwd_kernel(const LnBwdArgs a) {
+  __shared__ float sh[4];
+  const int net = blockIdx.y;
+  const float* __restrict__ Hm = a.Hact[net];
+  const float* __restrict__ xh = a.xhat[net];
+  const float* __restrict__ g = a.gamma[net];
+  const bool top = a.dH[net] == nullptr;
+  float gam[LN_MAX_COLS], hw[LN_MAX_COLS], dg[LN_MAX_COLS], db[LN_MAX_COLS], dh[LN_MAX_COLS];
+#pragma unroll
+  for (int c = 0; c < LN_MAX_COLS; ++c) {
+    const int j = threadIdx.x + 256 * c;
+    gam[c] = j < a.H ? g[j] : 0.f;
+    hw[c] = (top && j < a.H) ? a.headw[net][j] : 0.f;
+    dg[c] = db[c] = dh[c] = 0.f;
+  }
+  const int row0 = blockIdx.x * a.rows_per_block, row1 = min(a.B, row0 + a.rows_per_block);
+  const float invH = 1.f / (float)a.H;
+  for (int b = row0; b < row1; ++b) {
+    const float dvb = top ? a.dv[net][b] : 0.f;
+    float dxh[LN_MAX_COLS], x[LN_MAX_COLS];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_COLS; ++c) {
+      const int j = threadIdx.x + 256 * c;
+      dxh[c] = 0.f; x[c] = 0.f;
+      if (j < a.H) {
+        const size_t o = (size_t)b * a.ld + j;
+        const float h = Hm[o];
+        const float up = top ? dvb * hw[c] : a.dH[net][o];
+        const float dy = h > 0.f ? up : 0.f;
+        x[c] = xh[o];
+        dg[c] += dy * x[c];
+        db[c] += dy;
+        if (top) dh[c] += dvb * h;
+        dxh[c] = dy * gam[c];
+        s1 += dxh[c];
+        s2 += dxh[c] * x[c];
+      }
+    }
+    const float m1 = block_sum_256(s1, sh) * invH;
+    const float m2 = block_sum_256(s2, sh) * invH;
+    const float rs = a.rstd[net][b];
+#pragma unroll
+    for (int c = 0; c < LN_MAX_COLS; ++c) {
+      const int j = threadIdx.x + 256 * c;
+      if (j < a.H) a.dZ[net][(size_t)b * a.ld + j] = (dxh[c] - m1 - x[c] * m2) * rs;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < LN_MAX_COLS; ++c) {
+    const int j = threadIdx.x + 256 * c;
+    if (j < a.H) {
+      const size_t o = (size_t)blockIdx.x * a.H + j;
+      a.part_dgamma[net][o] = dg[c];
+      a.part_dbeta[net][o] = db[c];
+      if (top) a.part_dhead[net][o] = dh[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // CQL(H) on a plain-DQN TD loss for discrete actions  (src/porl/train/cql_trainer.py:60-124)
 //   y = r + gamma * max_a Q_tgt(s', a) * (1 - d);  td = mean((Q(s)[a] - y)^2)
 //   pen = mean(logsumexp_a Q(s, a) - ln A - Q(s)[a]);  loss = td + alpha * pen

@@ -80,6 +80,7 @@ struct ProfScope {
 constexpr int NUM_CU = 256;
 constexpr int SK_MAX = 16;
 constexpr int NLL_ROWS_PER_BLOCK = 4;    // one row per wave
+constexpr int LN_ROWS_PER_BLOCK = 8;
 
 inline int64_t ru4(int64_t x) { return (x + 3) & ~int64_t(3); }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -126,6 +127,8 @@ struct Workspace {
   int64_t target_v, dv[2], dmu;
   int64_t slab_mean, slab_a, slab_b;
   int64_t part_loss, part_min, part_dls;
+  int64_t xhat_v[2][PORL_MAX_HIDDEN], rstd_v[2][PORL_MAX_HIDDEN];   // LayerNorm only
+  int64_t ln_dg[2], ln_db[2], ln_dh[2];
   int64_t total;
 };
 
@@ -228,12 +231,14 @@ int check_ready(const porl_iql* h, bool need_batch) {
   return 0;
 }
 
-// One hidden layer of up to 4 MLPs as one grouped launch.
+// One hidden layer of up to 4 MLPs as one grouped launch (+ one LayerNorm launch for the nets that have it).
 struct FwdNet {
   const float* in; int ldin;       // (B, K)
   const float* W; const float* b;  // (H, K), (H)
-  float* out;                      // (B, Hp) or null when only the head is needed
+  float* out;                      // (B, Hp); may be null without LayerNorm when only the head is needed
   const float* headw; float* headout;
+  const float* ln_g = nullptr; const float* ln_b = nullptr;   // LayerNorm affine (null = no LayerNorm)
+  float* xhat = nullptr; float* rstd = nullptr;              // kept for backward when non-null
 };
 
 int fwd_hidden_layer(porl_iql* h, const FwdNet* nets, int nnets, int B, int K, bool last, int* parts_out,
@@ -241,17 +246,35 @@ int fwd_hidden_layer(porl_iql* h, const FwdNet* nets, int nnets, int B, int K, b
   const int H = h->cfg.hidden_dim;
   GemmGroup g{};
   g.nprob = nnets;
+  bool any_ln = false;
   for (int n = 0; n < nnets; ++n) {
+    const bool ln = nets[n].ln_g != nullptr;
+    any_ln = any_ln || ln;
     GemmProb p = make_prob(GEMM_NT, nets[n].in, nets[n].ldin, nets[n].W, K, nets[n].out, h->Hp, B, H, K);
     p.bias = nets[n].b;
-    p.act = ACT_RELU;
+    p.act = ln ? ACT_NONE : ACT_RELU;
     p.store_c = nets[n].out != nullptr;
-    if (last && nets[n].headw) { p.headw = nets[n].headw; p.headout = nets[n].headout; }
+    if (ln && !nets[n].out) PORL_FAIL(PORL_ERR_INVALID, "LayerNorm needs a pre-activation buffer");
+    if (!ln && last && nets[n].headw) { p.headw = nets[n].headw; p.headout = nets[n].headout; }
     g.p[n] = p;
   }
   const int tile = pick_tile(g);
-  if (parts_out) *parts_out = head_parts(H, tile);
-  return launch_group(g, tile, s);
+  if (parts_out) *parts_out = any_ln ? 1 : head_parts(H, tile);
+  PORL_TRY(launch_group(g, tile, s));
+  if (any_ln) {
+    LnFwdArgs a{};
+    for (int n = 0; n < nnets; ++n) {
+      if (!nets[n].ln_g) continue;
+      const int k = a.nnets++;
+      a.Z[k] = nets[n].out; a.xhat[k] = nets[n].xhat; a.rstd[k] = nets[n].rstd;
+      a.gamma[k] = nets[n].ln_g; a.beta[k] = nets[n].ln_b;
+      a.headw[k] = last ? nets[n].headw : nullptr; a.headb[k] = nullptr; a.headout[k] = nets[n].headout;
+    }
+    a.B = B; a.H = H; a.ld = h->Hp; a.rows_per_block = LN_ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(ln_relu_fwd_kernel, dim3(cdiv(B, LN_ROWS_PER_BLOCK), a.nnets), dim3(256), 0, s, a);
+    PORL_HIP(hipGetLastError());
+  }
+  return 0;
 }
 
 }  // namespace
@@ -268,7 +291,8 @@ int porl_iql_create(const porl_iql_cfg* c, porl_iql** out) {
     PORL_FAIL(PORL_ERR_INVALID, "dimensions must be positive");
   if (c->n_hidden < 1 || c->n_hidden > PORL_MAX_HIDDEN) PORL_FAIL(PORL_ERR_INVALID, "n_hidden must be in [1,%d]", PORL_MAX_HIDDEN);
   if (c->pol_out_dim > 64 * NLL_MAX_COLS_PER_LANE) PORL_FAIL(PORL_ERR_UNSUPPORTED, "pol_out_dim > %d", 64 * NLL_MAX_COLS_PER_LANE);
-  if (c->layer_norm) PORL_FAIL(PORL_ERR_UNSUPPORTED, "layer_norm=True is not implemented on device yet");
+  if (c->layer_norm && c->hidden_dim > 256 * LN_MAX_COLS)
+    PORL_FAIL(PORL_ERR_UNSUPPORTED, "layer_norm with hidden_dim > %d", 256 * LN_MAX_COLS);
   porl_iql* h = new porl_iql();
   h->cfg = *c;
   const int S = c->obs_dim, D = c->pol_out_dim, H = c->hidden_dim, L = c->n_hidden, B = c->max_batch;
@@ -306,6 +330,13 @@ int porl_iql_create(const porl_iql_cfg* c, porl_iql** out) {
   w.slab_b = take((int64_t)SK_MAX * ((int64_t)D * H + D + 8));
   const int nblk = cdiv(B, NLL_ROWS_PER_BLOCK);
   w.part_loss = take(nblk); w.part_min = take(nblk); w.part_dls = take((int64_t)nblk * D);
+  if (c->layer_norm) {
+    const int nln = cdiv(B, LN_ROWS_PER_BLOCK);
+    for (int i = 0; i < 2; ++i) {
+      for (int l = 0; l < L; ++l) { w.xhat_v[i][l] = take(BH); w.rstd_v[i][l] = take(B); }
+      w.ln_dg[i] = take((int64_t)nln * H); w.ln_db[i] = take((int64_t)nln * H); w.ln_dh[i] = take((int64_t)nln * H);
+    }
+  }
   w.total = o;
   *out = h;
   return PORL_OK;
@@ -369,6 +400,75 @@ int porl_iql_load_batch(porl_iql* h, int32_t batch, const float* obs, int64_t ob
   return PORL_OK;
 }
 
+// LayerNorm variant of the value backward: dZ of every hidden layer is materialised by the LayerNorm
+// backward kernel (row statistics), gamma/beta/(head) gradients come from its per-block partial sums.
+static int value_backward_ln(porl_iql* h, const porl_iql_hyper* hp, hipStream_t s) {
+  (void)hp;
+  const int B = h->batch, S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden, Hp = h->Hp;
+  float* W = h->buf.workspace;
+  const Workspace& ws = h->ws;
+  const float* Pv = h->buf.params_vf;
+  float* Gv = h->buf.grads_vf;
+  const int nln = cdiv(B, LN_ROWS_PER_BLOCK);
+  for (int l = L - 1; l >= 0; --l) {
+    const bool top = l == L - 1;
+    const int Kin = l == 0 ? S : H;
+    {
+      LnBwdArgs a{};
+      a.nnets = 2;
+      for (int i = 0; i < 2; ++i) {
+        a.dH[i] = top ? nullptr : W + ws.dz_v[i][0];
+        a.dv[i] = W + ws.dv[i]; a.headw[i] = Pv + h->v[i].w[L];
+        a.Hact[i] = W + ws.act_v[i][l]; a.xhat[i] = W + ws.xhat_v[i][l]; a.rstd[i] = W + ws.rstd_v[i][l];
+        a.gamma[i] = Pv + h->v[i].lnw[l];
+        a.dZ[i] = W + ws.dz_v[i][1];
+        a.part_dgamma[i] = W + ws.ln_dg[i]; a.part_dbeta[i] = W + ws.ln_db[i]; a.part_dhead[i] = W + ws.ln_dh[i];
+      }
+      a.B = B; a.H = H; a.ld = Hp; a.rows_per_block = LN_ROWS_PER_BLOCK;
+      hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(nln, 2), dim3(256), 0, s, a);
+      PORL_HIP(hipGetLastError());
+      ReduceArgs r{};
+      for (int i = 0; i < 2; ++i) {
+        add_reduce(r, Gv + h->v[i].lnw[l], W + ws.ln_dg[i], H, H, nln);
+        add_reduce(r, Gv + h->v[i].lnb[l], W + ws.ln_db[i], H, H, nln);
+        if (top) add_reduce(r, Gv + h->v[i].w[L], W + ws.ln_dh[i], H, H, nln);
+      }
+      PORL_TRY(launch_reduce(r, s));
+    }
+    ReduceArgs red{};
+    GemmGroup g{};
+    for (int i = 0; i < 2; ++i) {
+      const float* dz = W + ws.dz_v[i][1];
+      const float* in = l == 0 ? W + ws.xs : W + ws.act_v[i][l - 1];
+      const int ldin = l == 0 ? h->Sp : Hp;
+      GemmProb p = make_prob(GEMM_TN, dz, Hp, in, ldin, Gv + h->v[i].w[l], Kin, H, Kin, B);
+      p.colsum = Gv + h->v[i].b[l];
+      g.p[g.nprob++] = p;
+      if (l > 0)   // unmasked: the ReLU mask of layer l-1 is applied by its own LayerNorm backward
+        g.p[g.nprob++] = make_prob(GEMM_NN, dz, Hp, Pv + h->v[i].w[l], Kin, W + ws.dz_v[i][0], Hp, B, Kin, H);
+    }
+    const int tile = pick_tile(g);
+    if (l == 0) {
+      int bm, bn;
+      tile_dims(tile, bm, bn);
+      const int sk = pick_splitk(H, Kin, B, 2, bm, bn);
+      if (sk > 1) {
+        const int64_t per = (int64_t)H * Kin, perc = H;
+        for (int i = 0; i < 2; ++i) {
+          float* slabW = W + ws.slab_a + (int64_t)i * SK_MAX * (per + 2 * perc + 8);
+          float* slabC = slabW + (int64_t)SK_MAX * per;
+          g.p[i].splitk = sk; g.p[i].C = slabW; g.p[i].colsum = slabC;
+          add_reduce(red, Gv + h->v[i].w[0], slabW, per, per, sk);
+          add_reduce(red, Gv + h->v[i].b[0], slabC, perc, perc, sk);
+        }
+      }
+    }
+    PORL_TRY(launch_group(g, tile, s));
+    PORL_TRY(launch_reduce(red, s));
+  }
+  return PORL_OK;
+}
+
 static int feistel_half_bits(int64_t n_rows) {
   int bits = 1;
   while ((int64_t(1) << bits) < n_rows) ++bits;
@@ -418,6 +518,7 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
   const float* Pt = h->buf.params_tgt;
   float* Gv = h->buf.grads_vf;
   int parts = 0;
+  const bool LN = h->cfg.layer_norm != 0;
 
   // -- forward: target twins on s', online twins on s — 4 nets per launch ---------------------------
   for (int l = 0; l < L; ++l) {
@@ -432,9 +533,13 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
       else { f.in = W + (tgt ? ws.act_t[i][(l - 1) & 1] : ws.act_v[i][l - 1]); f.ldin = Hp; }
       f.W = P + h->v[i].w[l]; f.b = P + h->v[i].b[l];
       const bool last = l == L - 1;
-      f.out = tgt ? (last ? nullptr : W + ws.act_t[i][l & 1]) : W + ws.act_v[i][l];
+      f.out = tgt ? ((last && !LN) ? nullptr : W + ws.act_t[i][l & 1]) : W + ws.act_v[i][l];
       f.headw = P + h->v[i].w[L];
       f.headout = W + (tgt ? ws.hp_t[i] : ws.hp_v[i]);
+      if (LN) {
+        f.ln_g = P + h->v[i].lnw[l]; f.ln_b = P + h->v[i].lnb[l];
+        if (!tgt) { f.xhat = W + ws.xhat_v[i][l]; f.rstd = W + ws.rstd_v[i][l]; }
+      }
     }
     PORL_TRY(fwd_hidden_layer(h, nets, 4, B, K, l == L - 1, &parts, s));
   }
@@ -459,6 +564,7 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
   // -- hidden layers, top down.  dZ of the top layer is never materialised: it is the rank-1 prologue
   //    dv[b] * w_L[j] * 1[H_{L-1}[b,j] > 0] applied while staging H_{L-1}. ----------------------------
   ReduceArgs red{};
+  if (LN) return value_backward_ln(h, hp, s);
   for (int l = L - 1; l >= 0; --l) {
     const bool top = l == L - 1;
     const int Kin = l == 0 ? S : H;
@@ -579,6 +685,7 @@ int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream
   const float* Pp = h->buf.params_pol;
   float* Gp = h->buf.grads_pol;
   int parts = 0;
+  const bool LN = h->cfg.layer_norm != 0;
 
   // -- forward: updated twins (head only) + policy hidden layers, 3 nets per launch ----------------
   for (int l = 0; l < L; ++l) {
@@ -590,8 +697,9 @@ int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream
       if (l == 0) { f.in = W + ws.xs; f.ldin = h->Sp; }
       else { f.in = W + ws.act_t[i][(l - 1) & 1]; f.ldin = Hp; }       // target scratch is free now
       f.W = Pv + h->v[i].w[l]; f.b = Pv + h->v[i].b[l];
-      f.out = last ? nullptr : W + ws.act_t[i][l & 1];
+      f.out = (last && !LN) ? nullptr : W + ws.act_t[i][l & 1];
       f.headw = Pv + h->v[i].w[L]; f.headout = W + ws.hp_v[i];
+      if (LN) { f.ln_g = Pv + h->v[i].lnw[l]; f.ln_b = Pv + h->v[i].lnb[l]; }
     }
     FwdNet& f = nets[2];
     if (l == 0) { f.in = W + ws.xs; f.ldin = h->Sp; }
@@ -719,8 +827,10 @@ int porl_iql_forward_value(porl_iql* h, int which, const float* x, int64_t x_rs,
       if (l == 0) { f.in = W + h->ws.xn; f.ldin = h->Sp; }
       else { f.in = W + h->ws.act_t[i][(l - 1) & 1]; f.ldin = h->Hp; }
       f.W = P + h->v[i].w[l]; f.b = P + h->v[i].b[l];
-      f.out = l == L - 1 ? nullptr : W + h->ws.act_t[i][l & 1];
+      const bool LN = h->cfg.layer_norm != 0;
+      f.out = (l == L - 1 && !LN) ? nullptr : W + h->ws.act_t[i][l & 1];
       f.headw = P + h->v[i].w[L]; f.headout = W + h->ws.hp_t[i];
+      if (LN) { f.ln_g = P + h->v[i].lnw[l]; f.ln_b = P + h->v[i].lnb[l]; }
     }
     PORL_TRY(fwd_hidden_layer(h, nets, 2, batch, l == 0 ? S : H, l == L - 1, &parts, s));
   }

@@ -41,9 +41,9 @@ def test_layout_matches_module_parameters():
     from porl_amd.engine import IqlEngine
     from porl_amd.agent.value_functions import TwinV
     from porl_amd.agent.policy import GaussianPolicy
-    for S, D, H, L in [(60, 60, 1024, 2), (17, 5, 48, 3), (362, 2, 64, 1)]:
-        eng = IqlEngine(S, D, H, L, max_batch=8)
-        vf, pol = TwinV(S, hidden_dim=H, n_hidden=L), GaussianPolicy(S, D, hidden_dim=H, n_hidden=L)
+    for S, D, H, L, ln in [(60, 60, 1024, 2, False), (17, 5, 48, 3, False), (362, 2, 64, 1, False), (60, 60, 64, 2, True)]:
+        eng = IqlEngine(S, D, H, L, layer_norm=ln, max_batch=8)
+        vf, pol = TwinV(S, layer_norm=ln, hidden_dim=H, n_hidden=L), GaussianPolicy(S, D, hidden_dim=H, n_hidden=L)
         for mod, group, total in ((vf, 0, eng.n_vf), (pol, 1, eng.n_pol)):
             table = eng.tensor_table(group)
             shapes = [tuple(p.shape) for p in mod.parameters()]
@@ -66,7 +66,8 @@ def test_invalid_and_unsupported_configs():
     with pytest.raises(N.NativeError):
         IqlEngine(0, 60, 64, 2)
     with pytest.raises(N.NativeError, match="layer_norm"):
-        IqlEngine(60, 60, 64, 2, layer_norm=True)     # not on device yet: fails loudly, no fallback
+        IqlEngine(60, 60, 4096, 2, layer_norm=True)   # wider than the LayerNorm kernels: fails loudly, no fallback
+    IqlEngine(60, 60, 1024, 2, layer_norm=True)
 
 
 def test_no_cpu_fallback():

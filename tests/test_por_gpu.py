@@ -50,10 +50,10 @@ def _cmp_params_robust(got, truth, frac_tol=1e-3, elem_tol=2e-6, max_tol=5e-5):
         assert float(err.max()) <= max_tol, f"{k}: max-abs {err.max():.3e}"
 
 
-def _oracle64(init, S, H, L, **kw):
+def _oracle64(init, S, H, L, ln=False, **kw):
     import oracle.por_oracle as O
     O.set_precision(np.float64)
-    return PorOracle({k: np.asarray(v, np.float64) for k, v in init.items()}, S, H, L, **kw)
+    return PorOracle({k: np.asarray(v, np.float64) for k, v in init.items()}, S, H, L, ln, **kw)
 
 
 @pytest.fixture(autouse=True)
@@ -63,18 +63,19 @@ def _restore_precision():
     O.set_precision(np.float32)
 
 
-def _make_por(S, H, L, B, seed=0, **kw):
+def _make_por(S, H, L, B, seed=0, ln=False, **kw):
     from porl_amd.agent.por import POR
     torch.manual_seed(seed)
-    return POR(_args(S, H, L, B=B), kw.pop("max_steps", 1000), kw.pop("tau", 0.9), kw.pop("alpha", 10.0),
+    return POR(_args(S, H, L, ln=ln, B=B), kw.pop("max_steps", 1000), kw.pop("tau", 0.9), kw.pop("alpha", 10.0),
                device=DEV, **kw)
 
 
-@pytest.mark.parametrize("name", ["por_s60_h64_b32", "por_s17_h48_l3_b50"])
+@pytest.mark.parametrize("name", ["por_s60_h64_b32", "por_s17_h48_l3_b50", "por_s60_h64_b32_ln"])
 def test_por_matches_reference_golden(name):
     z, meta = load_golden(name)
     S, H, L, B, K, A = (int(meta[k]) for k in ("S", "H", "L", "B", "K", "A"))
-    agent = _make_por(S, H, L, B, seed=int(meta["seed_model"]), tau=meta["tau"], alpha=meta["alpha"])
+    agent = _make_por(S, H, L, B, seed=int(meta["seed_model"]), ln=bool(meta["layer_norm"]), tau=meta["tau"],
+                      alpha=meta["alpha"])
     init = sub(z, "init/")
     _cmp_params(_np_sd(agent), init, atol=0.0)         # same seed -> the reference's initial weights
     rows = torch.from_numpy(make_rows(K * B, S, A, seed=int(meta["seed_data"]))).to(DEV)
@@ -153,26 +154,31 @@ def _phase_check(agent, o, s, sp, r, d, tag):
     _cmp_params_robust(_np_sd(agent), o.P)
 
 
-@pytest.mark.parametrize("S,H,L,B", [(60, 64, 2, 32), (60, 256, 2, 256), (17, 48, 3, 50), (60, 128, 1, 100),
-                                     (362, 64, 2, 16), (60, 1024, 2, 1024), (60, 512, 3, 2048)])
-def test_por_phases_vs_oracle(S, H, L, B):
-    agent = _make_por(S, H, L, B)
-    o = _oracle64(_np_sd(agent), S, H, L)
+@pytest.mark.parametrize("S,H,L,B,ln", [(60, 64, 2, 32, False), (60, 256, 2, 256, False), (17, 48, 3, 50, False),
+                                        (60, 128, 1, 100, False), (362, 64, 2, 16, False),
+                                        (60, 1024, 2, 1024, False), (60, 512, 3, 2048, False),
+                                        (60, 64, 2, 32, True), (17, 48, 3, 50, True), (60, 100, 1, 37, True),
+                                        (60, 1024, 2, 1024, True)])
+def test_por_phases_vs_oracle(S, H, L, B, ln):
+    agent = _make_por(S, H, L, B, ln=ln)
+    o = _oracle64(_np_sd(agent), S, H, L, ln)
     rows = torch.from_numpy(make_rows(3 * B, S, 2, seed=7)).to(DEV)
     for k in range(3):
         s, r, sp, d, a = split_rows(rows[k * B:(k + 1) * B], S, 2)
         _phase_check(agent, o, s, sp, r, d, f"step{k}")
 
 
-@pytest.mark.parametrize("name", ["por_s60_h256_b256", "por_s60_h1024_b256", "por_s60_h1024_b1024"])
+@pytest.mark.parametrize("name", ["por_s60_h256_b256", "por_s60_h1024_b256", "por_s60_h1024_b1024",
+                                  "por_s60_h1024_b1024_ln"])
 def test_por_baseline_configs_vs_golden_losses(name):
     """BASELINE configs 1/2 (H=1024, B=256/1024): losses against the reference's recorded values and
     all 5.6 M parameters against the fp64 run of the oracle (whose fp32 run is pinned to the reference's
     checksums in tests/test_oracle_golden.py)."""
     z, meta = load_golden(name)
     S, H, L, B, K, A = (int(meta[k]) for k in ("S", "H", "L", "B", "K", "A"))
-    agent = _make_por(S, H, L, B, seed=int(meta["seed_model"]))
-    o = _oracle64(_np_sd(agent), S, H, L)
+    ln = bool(meta["layer_norm"])
+    agent = _make_por(S, H, L, B, seed=int(meta["seed_model"]), ln=ln)
+    o = _oracle64(_np_sd(agent), S, H, L, ln)
     rows_np = make_rows(K * B, S, A, seed=int(meta["seed_data"])).astype(np.float64)
     rows = torch.from_numpy(rows_np.astype(np.float32)).to(DEV)
     for k in range(K):
