@@ -1,0 +1,69 @@
+"""Data-parallel update on the device: 2 ranks (both on cuda:0, gloo exchange of CUDA tensors — the box has
+one GPU; RCCL needs one device per rank) against the single-process update on the concatenated minibatch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+S, H, L, BL, STEPS = 60, 128, 2, 64, 3
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _rows():
+    from porl_amd.util.synth import make_rows
+    return make_rows(2 * STEPS * BL, S, 2, seed=21)
+
+
+def _agent(B):
+    from types import SimpleNamespace
+    from porl_amd.agent.por import POR
+    torch.manual_seed(0)
+    return POR(SimpleNamespace(state_size=S, hidden_dim=H, n_hidden=L, layer_norm=False, action_size=2, max_batch=B),
+               1000, 0.9, 10.0, device=torch.device("cuda"))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    import torch.distributed as dist
+    from porl_amd.util.synth import split_rows
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    agent = _agent(BL)
+    rows = torch.from_numpy(_rows()).cuda()
+    losses = []
+    for k in range(STEPS):
+        glob = rows[k * world * BL:(k + 1) * world * BL]
+        local = glob[rank * BL:(rank + 1) * BL]              # this rank's shard of the global minibatch
+        s, r, sp, d, _ = split_rows(local, S, 2)
+        losses.append(agent.por_residual_update(s, sp, r, d))
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "dp.npz"), losses=np.array(losses),
+                 **{k: v.cpu().numpy() for k, v in agent.state_dict().items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_update_equals_global_batch_update(tmp_path):
+    from porl_amd.util.synth import split_rows
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "dp.npz")
+    agent = _agent(world * BL)
+    rows = torch.from_numpy(_rows()).cuda()
+    for k in range(STEPS):
+        s, r, sp, d, _ = split_rows(rows[k * world * BL:(k + 1) * world * BL], S, 2)
+        loss = agent.por_residual_update(s, sp, r, d)
+        np.testing.assert_allclose(got["losses"][k], loss, rtol=2e-6)
+    for k, v in agent.state_dict().items():
+        np.testing.assert_allclose(got[k], v.cpu().numpy(), atol=2e-6, err_msg=k)
