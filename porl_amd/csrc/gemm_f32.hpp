@@ -62,6 +62,7 @@ struct GemmProb {
   int store_c;
   int a_vec, b_vec;       // 16-byte loads allowed (pointer and ld aligned)
   int a_kc, b_kc;         // operand is k-contiguous ((M,K)/(N,K)) vs m/n-contiguous ((K,M)/(K,N))
+  int c_vec;              // filled by plan_group: C (and mask) may be accessed with 16-byte operations
   // filled by the host planner
   int tiles_m, tiles_n, block_start, kchunk;
 };
@@ -81,11 +82,42 @@ __host__ __device__ constexpr int lds_stride(int R) { return R + 4; }
 // dimension).  Built once before the K loop from the problem's layout flag, so the loop itself is
 // straight-line code: loads are issued back to back and waited for only after the MFMAs.
 struct StageSlot {
-  const float* ptr;   // address of element 0 in K-tile 0
+  unsigned off;       // byte offset of element 0 from the operand's K-tile base (uniform pointer, see tile_base)
   int kpos;           // k index of element 0 in K-tile 0 (absolute)
   int cpos;           // index along the non-k dimension of element 0
   int lds;            // LDS offset (floats) of element 0
 };
+
+// Operand staging goes through raw buffer loads: address = resource base (SGPRs) + per-tile scalar offset
+// + 32-bit lane offset, so the loop spends no vector ALU on addresses (every VALU op between two f32
+// MFMAs costs ~13 cycles, scripts/mfma_fill.hip), and a lane whose offset is past `num_records` simply
+// reads 0.0 — the hardware range check replaces per-element selects on edge tiles.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned BUF_OOB = 0x80000000u;          // lane offset that is out of range for every resource
+
+// LLVM's raw buffer-load intrinsics, bound by name (the float-typed forms; clang's
+// __builtin_amdgcn_raw_buffer_load_b128 is narrowed to one dword by ROCm 7.2's optimiser)
+__device__ f32x4 llvm_raw_buffer_load_v4f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float llvm_raw_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+
+typedef i32x4 BufRsrc;
+__device__ __forceinline__ BufRsrc make_rsrc(const float* p, size_t bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  BufRsrc r;
+  r.x = (int)(unsigned)(a & 0xFFFFFFFFull);
+  r.y = (int)(unsigned)((a >> 32) & 0xFFFFull);         // stride 0: raw buffer, offset checked against num_records
+  r.z = (int)(bytes >= 0x7FFFFFFFull ? 0x7FFFFFFFu : (unsigned)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ float4 buf_ld128(BufRsrc r, unsigned voff, unsigned soff) {
+  const f32x4 v = llvm_raw_buffer_load_v4f32(r, (int)voff, (int)soff, 0);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float buf_ld32(BufRsrc r, unsigned voff, unsigned soff) {
+  return llvm_raw_buffer_load_f32(r, (int)voff, (int)soff, 0);
+}
 
 template <bool V> struct BoolTag { static constexpr bool value = V; };
 template <int V> struct IntTag { static constexpr int value = V; };
@@ -176,17 +208,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
   const int b_dk = b_kc ? 1 : 0, b_dc = 1 - b_dk;
   const size_t a_step = a_kc ? (size_t)BK : (size_t)BK * P.lda;   // pointer advance per K-tile
   const size_t b_step = b_kc ? (size_t)BK : (size_t)BK * P.ldb;
+  // buffer resources over the whole operands and the scalar byte offset of K-tile kt
+  const BufRsrc a_rsrc = make_rsrc(Ag, (size_t)(a_kc ? M : P.K) * P.lda * sizeof(float));
+  const BufRsrc b_rsrc = make_rsrc(Bg, (size_t)(b_kc ? N : P.K) * P.ldb * sizeof(float));
+  const unsigned a_org = (unsigned)((a_kc ? (size_t)ks : (size_t)ks * P.lda) * sizeof(float));
+  const unsigned b_org = (unsigned)((b_kc ? (size_t)ks : (size_t)ks * P.ldb) * sizeof(float));
+  auto a_soff = [&](int kt) { return a_org + (unsigned)(kt * a_step * sizeof(float)); };
+  auto b_soff = [&](int kt) { return b_org + (unsigned)(kt * b_step * sizeof(float)); };
 #pragma unroll
   for (int i = 0; i < NLA; ++i) {
     const int f = t + THREADS * i;
     if (a_kc) {
       const int kq = f % (BK / 4), row = f / (BK / 4);
       sa[i].kpos = ks + kq * 4; sa[i].cpos = m0 + row; sa[i].lds = row * SK + kq * 4;
-      sa[i].ptr = Ag + (size_t)(m0 + row) * P.lda + (ks + kq * 4);
+      sa[i].off = (unsigned)(((size_t)(m0 + row) * P.lda + kq * 4) * sizeof(float));
     } else {
       const int c4 = f % (BM / 4), kr = f / (BM / 4);
       sa[i].kpos = ks + kr; sa[i].cpos = m0 + c4 * 4; sa[i].lds = kr * SA + c4 * 4;
-      sa[i].ptr = Ag + (size_t)(ks + kr) * P.lda + (m0 + c4 * 4);
+      sa[i].off = (unsigned)(((size_t)kr * P.lda + (m0 + c4 * 4)) * sizeof(float));
     }
   }
 #pragma unroll
@@ -195,11 +234,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
     if (b_kc) {
       const int kq = f % (BK / 4), row = f / (BK / 4);
       sb[i].kpos = ks + kq * 4; sb[i].cpos = n0 + row; sb[i].lds = row * SK + kq * 4;
-      sb[i].ptr = Bg + (size_t)(n0 + row) * P.ldb + (ks + kq * 4);
+      sb[i].off = (unsigned)(((size_t)(n0 + row) * P.ldb + kq * 4) * sizeof(float));
     } else {
       const int c4 = f % (BN / 4), kr = f / (BN / 4);
       sb[i].kpos = ks + kr; sb[i].cpos = n0 + c4 * 4; sb[i].lds = kr * SB + c4 * 4;
-      sb[i].ptr = Bg + (size_t)(ks + kr) * P.ldb + (n0 + c4 * 4);
+      sb[i].off = (unsigned)(((size_t)kr * P.ldb + (n0 + c4 * 4)) * sizeof(float));
     }
   }
 
@@ -226,9 +265,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
   const int a_off = wm * (BM / WM) + li;
   const int b_off = wn * (BN / WN) + li;
 
-  auto main_loop = [&](auto guard_tag, auto akc_tag, auto bkc_tag) {
+  auto main_loop = [&](auto guard_tag, auto akc_tag, auto bkc_tag, auto csum_tag) {
     constexpr bool GUARD = decltype(guard_tag)::value;
     constexpr bool AKC = decltype(akc_tag)::value;
+    constexpr bool CSUM = decltype(csum_tag)::value;    // accumulate column sums of A (bias gradient)
 
     // per-element validity of a slot in K-tile kt (GUARD only)
     auto slot_ok = [&](const StageSlot& s, int kadv, int dk, int dc, int cmax, bool (&ok)[4]) {
@@ -242,14 +282,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
     };
     // issue the loads of one slot; out-of-range lanes read `safe`; the result is not touched here, so
     // no wait is needed until store_tile
-    auto load_raw = [&](const StageSlot& s, const float* __restrict__ safe, size_t off, const bool (&ok)[4]) -> float4 {
+    // out-of-range lanes get an out-of-range offset: the buffer range check returns 0.0 for them
+    auto load_raw = [&](const StageSlot& s, BufRsrc r, unsigned soff, const bool (&ok)[4]) -> float4 {
       float4 v;
-      const float* p = s.ptr + off;
       if constexpr (VEC) {
-        v = *reinterpret_cast<const float4*>(ok[0] ? p : safe);
+        v = buf_ld128(r, ok[0] ? s.off : BUF_OOB, soff);
       } else {
-        v.x = *(ok[0] ? p : safe); v.y = *(ok[1] ? p + 1 : safe);
-        v.z = *(ok[2] ? p + 2 : safe); v.w = *(ok[3] ? p + 3 : safe);
+        v.x = buf_ld32(r, ok[0] ? s.off : BUF_OOB, soff);
+        v.y = buf_ld32(r, ok[1] ? s.off + 4u : BUF_OOB, soff);
+        v.z = buf_ld32(r, ok[2] ? s.off + 8u : BUF_OOB, soff);
+        v.w = buf_ld32(r, ok[3] ? s.off + 12u : BUF_OOB, soff);
       }
       return v;
     };
@@ -261,9 +303,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
         bool ok[4] = {true, true, true, true};
         if constexpr (GUARD) {
           slot_ok(sa[i], kadv, a_dk, a_dc, M, ok);
-          ra[i] = load_raw(sa[i], Ag, (size_t)kt * a_step, ok);
+          ra[i] = load_raw(sa[i], a_rsrc, a_soff(kt), ok);
         } else {
-          ra[i] = *reinterpret_cast<const float4*>(sa[i].ptr + (size_t)kt * a_step);
+          ra[i] = buf_ld128(a_rsrc, sa[i].off, a_soff(kt));
         }
         if constexpr (APRO) {
           const int k = sa[i].kpos + kadv, c = sa[i].cpos;
@@ -285,9 +327,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
         if constexpr (GUARD) {
           bool ok[4];
           slot_ok(sb[i], kadv, b_dk, b_dc, N, ok);
-          rb[i] = load_raw(sb[i], Bg, (size_t)kt * b_step, ok);
+          rb[i] = load_raw(sb[i], b_rsrc, b_soff(kt), ok);
         } else {
-          rb[i] = *reinterpret_cast<const float4*>(sb[i].ptr + (size_t)kt * b_step);
+          rb[i] = buf_ld128(b_rsrc, sb[i].off, b_soff(kt));
         }
       }
     };
@@ -300,11 +342,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
 #pragma unroll
       for (int i = 0; i < NLA; ++i) {
         float4 v = ra[i];
-        if constexpr (GUARD) {       // out-of-range lanes hold whatever sits at the operand base: zero them
-          bool ok[4];
-          slot_ok(sa[i], kadv, a_dk, a_dc, M, ok);
-          v.x = ok[0] ? v.x : 0.f; v.y = ok[1] ? v.y : 0.f; v.z = ok[2] ? v.z : 0.f; v.w = ok[3] ? v.w : 0.f;
-        }
         if constexpr (APRO) {
           const float rs = pr_rs[i];
           if constexpr (!AKC) {      // wgrad blocks also accumulate dv^T H for the output-layer weight
@@ -317,20 +354,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
         }
         ra[i] = v;
       }
-      if constexpr (GUARD) {
-#pragma unroll
-        for (int i = 0; i < NLB; ++i) {
-          bool ok[4];
-          slot_ok(sb[i], kadv, b_dk, b_dc, N, ok);
-          float4 v = rb[i];
-          v.x = ok[0] ? v.x : 0.f; v.y = ok[1] ? v.y : 0.f; v.z = ok[2] ? v.z : 0.f; v.w = ok[3] ? v.w : 0.f;
-          rb[i] = v;
-        }
-      }
 #pragma unroll
       for (int i = 0; i < NLA; ++i) {
         *reinterpret_cast<float4*>(As + sa[i].lds) = ra[i];
-        if constexpr (!AKC) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+        if constexpr (CSUM) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
       }
 #pragma unroll
       for (int i = 0; i < NLB; ++i) *reinterpret_cast<float4*>(Bs + sb[i].lds) = rb[i];
@@ -344,9 +371,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
         bool ok[4] = {true, true, true, true};
         if constexpr (GUARD) {
           slot_ok(sa[i], kadv, a_dk, a_dc, M, ok);
-          ra[i] = load_raw(sa[i], Ag, (size_t)kt * a_step, ok);
+          ra[i] = load_raw(sa[i], a_rsrc, a_soff(kt), ok);
         } else {
-          ra[i] = *reinterpret_cast<const float4*>(sa[i].ptr + (size_t)kt * a_step);
+          ra[i] = buf_ld128(a_rsrc, sa[i].off, a_soff(kt));
         }
         if constexpr (APRO) {
           const int k = sa[i].kpos + kadv, c = sa[i].cpos;
@@ -367,9 +394,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
         if constexpr (GUARD) {
           bool ok[4];
           slot_ok(sb[i], kadv, b_dk, b_dc, N, ok);
-          rb[i] = load_raw(sb[i], Bg, (size_t)kt * b_step, ok);
+          rb[i] = load_raw(sb[i], b_rsrc, b_soff(kt), ok);
         } else {
-          rb[i] = *reinterpret_cast<const float4*>(sb[i].ptr + (size_t)kt * b_step);
+          rb[i] = buf_ld128(b_rsrc, sb[i].off, b_soff(kt));
         }
       }
     };
@@ -380,11 +407,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
       if (q < NLA) {
         const int i = q;
         float4 v = ra[i];
-        if constexpr (GUARD) {
-          bool ok[4];
-          slot_ok(sa[i], kadv, a_dk, a_dc, M, ok);
-          v.x = ok[0] ? v.x : 0.f; v.y = ok[1] ? v.y : 0.f; v.z = ok[2] ? v.z : 0.f; v.w = ok[3] ? v.w : 0.f;
-        }
         if constexpr (APRO) {
           const float rs = pr_rs[i];
           if constexpr (!AKC) {
@@ -396,15 +418,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
           v.w = v.w > 0.f ? rs * pr_cs[i].w : 0.f;
         }
         *reinterpret_cast<float4*>(As + sa[i].lds) = v;
-        if constexpr (!AKC) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
+        if constexpr (CSUM) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
       } else {
         const int i = q - NLA;
         float4 v = rb[i];
-        if constexpr (GUARD) {
-          bool ok[4];
-          slot_ok(sb[i], kadv, b_dk, b_dc, N, ok);
-          v.x = ok[0] ? v.x : 0.f; v.y = ok[1] ? v.y : 0.f; v.z = ok[2] ? v.z : 0.f; v.w = ok[3] ? v.w : 0.f;
-        }
         *reinterpret_cast<float4*>(Bs + sb[i].lds) = v;
       }
     };
@@ -468,8 +485,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
     //   g = 0 : park tile it+1 (requested during the previous iteration) in the free LDS buffer
     //   g = 1 : request tile it+2 into the same staging registers  (>= 2.5 groups ahead of its use)
     //   every g: read the fragments of group g+1;  g = NG-1: barrier, then group 0 of the next tile
-    auto filler = [&](int it, int g, int m, bool has_next, bool has_next2) {
-      const int buf = it & 1;
+    auto filler = [&](int it, int buf, int g, int m, bool has_next, bool has_next2) {
       auto span = [&](int n_items, int first_m, int last_m, int& lo, int& hi) {   // items for MFMA m
         const int w = last_m - first_m;                                           // slots available
         if (m < first_m || m >= last_m) { lo = hi = 0; return; }
@@ -507,7 +523,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
 
     // the body is instantiated twice — with and without a following tile — so that no filler sits
     // behind a branch (a branch would make the compiler drain vmcnt before every request)
-    auto iteration = [&](int it, auto next_tag, auto next2_tag) {
+    // The body exists for both LDS buffers and for "tile it+1 / it+2 exists" separately: the buffer index is a
+    // compile-time constant (LDS addresses become immediates) and no filler sits behind a branch.
+    auto iteration = [&](int it, auto buf_tag, auto next_tag, auto next2_tag) {
+      constexpr int BUF = decltype(buf_tag)::value;
       constexpr bool HAS_NEXT = decltype(next_tag)::value, HAS_NEXT2 = decltype(next2_tag)::value;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
@@ -527,7 +546,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
               acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][n][j], acc[i][n], 0, 0, 0);
 #endif
               __builtin_amdgcn_sched_barrier(0);
-              filler(it, g, (j * WTM + i) * WTN + n, HAS_NEXT, HAS_NEXT2);
+              filler(it, BUF, g, (j * WTM + i) * WTN + n, HAS_NEXT, HAS_NEXT2);
               __builtin_amdgcn_sched_barrier(0);
             }
 #ifdef PORL_STAMP
@@ -535,23 +554,46 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
 #endif
       }
     };
-    for (int it = 0; it + 2 < nkt; ++it) iteration(it, BoolTag<true>{}, BoolTag<true>{});
-    if (nkt > 1) iteration(nkt - 2, BoolTag<true>{}, BoolTag<false>{});
-    if (nkt > 0) iteration(nkt - 1, BoolTag<false>{}, BoolTag<false>{});
+    using T = BoolTag<true>;
+    using F = BoolTag<false>;
+    using B0 = IntTag<0>;
+    using B1 = IntTag<1>;
+    int it = 0;
+    for (; it + 3 < nkt; it += 2) {                 // steady state: two K-tiles per trip, buffers 0 then 1
+      iteration(it, B0{}, T{}, T{});
+      iteration(it + 1, B1{}, T{}, T{});
+    }
+    const int rem = nkt - it;                       // 0..3 tiles left, `it` is even
+    if (rem == 3) {
+      iteration(it, B0{}, T{}, T{});
+      iteration(it + 1, B1{}, T{}, F{});
+      iteration(it + 2, B0{}, F{}, F{});
+    } else if (rem == 2) {
+      iteration(it, B0{}, T{}, F{});
+      iteration(it + 1, B1{}, F{}, F{});
+    } else if (rem == 1) {
+      iteration(it, B0{}, F{}, F{});
+    }
   };
 
   // one specialised copy of the loop per operand-layout pair (uniform per block)
   auto run = [&](auto guard_tag) {
     if (a_kc && b_kc) {
-      if constexpr (!APRO) main_loop(guard_tag, BoolTag<true>{}, BoolTag<true>{});   // forward: no prologue user
+      if constexpr (!APRO) main_loop(guard_tag, BoolTag<true>{}, BoolTag<true>{}, BoolTag<false>{});   // forward
     } else if (a_kc) {
-      main_loop(guard_tag, BoolTag<true>{}, BoolTag<false>{});
+      main_loop(guard_tag, BoolTag<true>{}, BoolTag<false>{}, BoolTag<false>{});
+    } else if (do_colsum) {   // only the tn == 0 column of blocks pays for the bias-gradient sums
+      main_loop(guard_tag, BoolTag<false>{}, BoolTag<false>{}, BoolTag<true>{});
     } else {
-      main_loop(guard_tag, BoolTag<false>{}, BoolTag<false>{});
+      main_loop(guard_tag, BoolTag<false>{}, BoolTag<false>{}, BoolTag<false>{});
     }
   };
-  if (full) run(BoolTag<false>{});
-  else run(BoolTag<true>{});
+  if constexpr (VEC) {
+    if (full) run(BoolTag<false>{});
+    else run(BoolTag<true>{});
+  } else {
+    run(BoolTag<true>{});
+  }
 #ifdef PORL_STAMP
   if (t == 0) { rt_loop1 = __builtin_amdgcn_s_memrealtime(); cy1 = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -591,6 +633,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
   const float* __restrict__ maskp = raw ? nullptr : P.mask;
   const int act = raw ? ACT_NONE : P.act;
   const bool store_c = P.store_c != 0;
+  // Interior tiles with a 16-byte-addressable C: the wave transposes its sub-tile through LDS (free after the
+  // last barrier of the main loop: nobody reads staged operands any more) and writes/reads C and the ReLU
+  // mask in full 16-byte rows instead of one dword per lane.
+  constexpr int WROWS = BM / WM, WCOLS = BN / WN, CS = WCOLS + 4;
+  static_assert(WM * WN * WROWS * CS <= 2 * (A_TILE + B_TILE), "C sub-tiles must fit in the staging LDS");
+  const bool fast_c = store_c && P.c_vec && (m0 + BM <= M) && (n0 + BN <= N);
+  float* ctile = lds + wave * (WROWS * CS);
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
     float hsum[16];
@@ -614,7 +663,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
         else if (act == ACT_TANH) v = tanhf(v);
         vals[r] = v;
       }
-      if (maskp) {
+      if (maskp && !fast_c) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -626,10 +675,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
 #pragma unroll
       for (int r = 0; r < 16; ++r) hsum[r] += vals[r] * hw;
       if (store_c) {
+        if (fast_c) {
+          // park the wave's sub-tile in LDS in row-major order; it leaves for memory as 16-byte rows below
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (row < M && col_ok) Cg[(size_t)row * P.ldc + col] = vals[r];
+          for (int r = 0; r < 16; ++r)
+            ctile[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * CS + j * 32 + li] = vals[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            if (row < M && col_ok) Cg[(size_t)row * P.ldc + col] = vals[r];
+          }
         }
       }
     }
@@ -653,6 +709,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
           if (row < M) P.headout[(size_t)part * M + row] = hsum[r];
         }
       }
+    }
+  }
+  if (fast_c) {
+    constexpr int C4 = WCOLS / 4;                  // float4 per sub-tile row
+    const int wr0 = m0 + wm * WROWS, wc0 = n0 + wn * WCOLS;
+#pragma unroll 4
+    for (int f = lane; f < WROWS * C4; f += 64) {
+      const int r = f / C4, c = (f % C4) * 4;
+      float4 v = *reinterpret_cast<const float4*>(ctile + r * CS + c);
+      if (maskp) {
+        const float4 mk = *reinterpret_cast<const float4*>(maskp + (size_t)(wr0 + r) * P.ldmask + wc0 + c);
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(Cg + (size_t)(wr0 + r) * P.ldc + wc0 + c) = v;
     }
   }
 #ifdef PORL_STAMP
@@ -713,6 +784,8 @@ inline int head_parts(int N, int tile) {
 }
 constexpr int HEAD_PARTS_PER_64_COLS = 2;   // upper bound: parts <= ceil(N/64) * 2 for every tile config
 
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 // Fill the planner fields; returns total blocks.
 inline int plan_group(GemmGroup& g, int tile) {
   int bm, bn;
@@ -726,6 +799,8 @@ inline int plan_group(GemmGroup& g, int tile) {
     int kc = (p.K + p.splitk - 1) / p.splitk;
     kc = ((kc + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
     p.kchunk = kc;
+    p.c_vec = aligned16(p.C) && (p.ldc % 4 == 0) && (p.splitk == 1 || ((size_t)p.M * p.ldc) % 4 == 0) &&
+              (p.mask == nullptr || (aligned16(p.mask) && p.ldmask % 4 == 0));
     p.block_start = start;
     start += p.tiles_m * p.tiles_n * p.splitk;
   }
@@ -746,10 +821,12 @@ inline hipError_t launch_tile(const GemmGroup& g, hipStream_t s) {
     vec = vec && g.p[i].a_vec && g.p[i].b_vec;
     if ((g.p[i].apro != APRO_NONE) != apro) return hipErrorInvalidValue;   // a group shares the prologue
   }
-  if (vec && !apro) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, true, false>), grid, block, pad, s, g);
-  else if (vec && apro) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, true, true>), grid, block, pad, s, g);
-  else if (!apro) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, false, false>), grid, block, pad, s, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, false, true>), grid, block, pad, s, g);
+  // The rank-1 A-operand prologue (APRO) is kept in the kernel source for reference but is no longer
+  // instantiated: VALU issued between f32 MFMAs is not free on gfx950, so the engine materialises dZ of the
+  // top layer with relu_head_bwd_kernel instead.
+  if (apro) return hipErrorInvalidValue;
+  if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, true, false>), grid, block, pad, s, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, false, false>), grid, block, pad, s, g);
   return hipGetLastError();
 }
 
@@ -765,8 +842,6 @@ inline hipError_t launch_gemm_group(int tile, GemmGroup& g, hipStream_t s) {
   }
   return hipErrorInvalidValue;
 }
-
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Convenience: a problem with defaults; the caller overrides epilogue fields.
 inline GemmProb make_prob(int mode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,

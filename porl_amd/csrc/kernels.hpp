@@ -67,6 +67,7 @@ __global__ __launch_bounds__(1024) void value_loss_kernel(const ValueLossArgs a)
   const float bt0 = a.b_t[0][0], bt1 = a.b_t[1][0], bv0 = a.b_v[0][0], bv1 = a.b_v[1][0];
   for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
     float t0 = 0.f, t1 = 0.f, v0 = 0.f, v1 = 0.f;
+#pragma unroll 8
     for (int p = 0; p < a.parts; ++p) {
       const size_t o = (size_t)p * a.B + b;
       t0 += a.hp_t[0][o]; t1 += a.hp_t[1][o]; v0 += a.hp_v[0][o]; v1 += a.hp_v[1][o];
@@ -202,11 +203,13 @@ __global__ __launch_bounds__(256) void policy_nll_kernel(const PolicyNllArgs a) 
   const int row0 = blockIdx.x * a.rows_per_block;
   const int row1 = min(a.B, row0 + a.rows_per_block);
   for (int b = row0 + wave; b < row1; b += 4) {
+    // head partial sums: lane p takes part p (parts <= 64), then a wave reduction — one load deep
     float v0 = 0.f, v1 = 0.f;
-    for (int p = 0; p < a.parts; ++p) {
+    for (int p = lane; p < a.parts; p += 64) {
       v0 += a.hp_v[0][(size_t)p * a.B + b];
       v1 += a.hp_v[1][(size_t)p * a.B + b];
     }
+    v0 = wave_sum(v0); v1 = wave_sum(v1);
     const float adv = a.target_v[b] - fminf(v0 + bv0, v1 + bv1);
     const float wgt = fminf(expf(a.weight_mode ? a.alpha * adv : adv / a.alpha), EXP_ADV_MAX);
     const float wb = wgt * a.inv_batch;
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(256) void policy_nll_kernel(const PolicyNllArgs a) 
       z[c] = 0.f; mu[c] = 0.f;
       if (c < ncl && j < a.D) {
         float m = a.mean_slab[(size_t)b * a.ldm + j];
+#pragma unroll 8
         for (int s = 1; s < a.nslab; ++s) m += a.mean_slab[(size_t)s * a.slab_stride + (size_t)b * a.ldm + j];
         m += mb[c];
         if (a.tanh_mean) m = tanhf(m);
@@ -339,15 +343,29 @@ struct ReduceJob {
 };
 struct ReduceArgs { int njobs; ReduceJob job[8]; };
 
-__global__ void multi_reduce_kernel(const ReduceArgs a) {
+// block = 32 outputs x 8 slab lanes: lane ty adds slabs ty, ty+8, ... (independent loads in flight), then the
+// 8 partial sums are combined in a fixed order through LDS — latency is nslab/8 loads deep, not nslab.
+__global__ __launch_bounds__(256) void multi_reduce_kernel(const ReduceArgs a) {
+  __shared__ float sh[8][33];
   const ReduceJob& j = a.job[blockIdx.y];
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < j.n; i += (long)gridDim.x * blockDim.x) {
-    float s = j.slab[i];
-    for (int k = 1; k < j.nslab; ++k) s += j.slab[(long)k * j.stride + i];
-    if (j.bias) s += j.bias[i % j.ncols];
-    if (j.act == 1) s = fmaxf(s, 0.f);
-    else if (j.act == 2) s = tanhf(s);
-    j.out[i] = s;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (long i0 = (long)blockIdx.x * 32; i0 < j.n; i0 += (long)gridDim.x * 32) {
+    const long i = i0 + tx;
+    float s = 0.f;
+    if (i < j.n)
+      for (int k = ty; k < j.nslab; k += 8) s += j.slab[(long)k * j.stride + i];
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < j.n) {
+      float t = sh[0][tx];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) t += sh[q][tx];
+      if (j.bias) t += j.bias[i % j.ncols];
+      if (j.act == 1) t = fmaxf(t, 0.f);
+      else if (j.act == 2) t = tanhf(t);
+      j.out[i] = t;
+    }
+    __syncthreads();
   }
 }
 
@@ -470,6 +488,62 @@ __global__ void sample_indices_kernel(int64_t n, int batch, uint64_t seed, uint6
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= batch) return;
   out[i] = base + feistel_index(n, i, seed, step, hb);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward through the scalar V head and the last ReLU:  dZ[b,j] = dv[b] * w[j] * 1[H[b,j] > 0], plus
+// per-block partial column sums of dv[b] * H[b,j] (the head's weight gradient).  One float4 of columns
+// per thread and pass; rows_per_block rows per block.  grid (ceil(B/rows), nets), block 256.
+// (Doing this inside the GEMM's operand loader costs ~20 VALU per staged float4, and VALU issued
+// between f32 MFMAs is not free: a separate 16 MB pass is cheaper.)
+// ---------------------------------------------------------------------------------------------------
+struct HeadBwdArgs {
+  const float* Hact[2]; const float* dv[2]; const float* w[2];
+  float* dZ[2]; float* part_dw[2];      // part_dw: [nblk][H]
+  int B, H, ld;
+};
+constexpr int HEAD_ROWS = 16;            // rows per block; all 16 row loads of a thread are in flight together
+
+__global__ __launch_bounds__(256) void relu_head_bwd_kernel(const HeadBwdArgs a) {
+  const int net = blockIdx.y;
+  const float* __restrict__ Hm = a.Hact[net];
+  const float* __restrict__ dv = a.dv[net];
+  float* __restrict__ dZ = a.dZ[net];
+  const int row0 = blockIdx.x * HEAD_ROWS;
+  const bool vec = (a.H & 3) == 0 && (a.ld & 3) == 0;
+  float d[HEAD_ROWS];
+#pragma unroll
+  for (int r = 0; r < HEAD_ROWS; ++r) d[r] = row0 + r < a.B ? dv[row0 + r] : 0.f;
+  for (int c0 = threadIdx.x * 4; c0 < a.H; c0 += 1024) {
+    float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f), acc = w4;
+    const int nv = min(4, a.H - c0);
+    if (vec) w4 = *reinterpret_cast<const float4*>(a.w[net] + c0);
+    else { float* wp = &w4.x; for (int q = 0; q < nv; ++q) wp[q] = a.w[net][c0 + q]; }
+    float4 h[HEAD_ROWS];
+#pragma unroll
+    for (int r = 0; r < HEAD_ROWS; ++r) {
+      h[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const size_t o = (size_t)(row0 + r) * a.ld + c0;
+      if (row0 + r < a.B) {
+        if (vec) h[r] = *reinterpret_cast<const float4*>(Hm + o);
+        else { float* hp = &h[r].x; for (int q = 0; q < nv; ++q) hp[q] = Hm[o + q]; }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < HEAD_ROWS; ++r) {
+      if (row0 + r >= a.B) continue;
+      const size_t o = (size_t)(row0 + r) * a.ld + c0;
+      float4 z;
+      z.x = h[r].x > 0.f ? d[r] * w4.x : 0.f; z.y = h[r].y > 0.f ? d[r] * w4.y : 0.f;
+      z.z = h[r].z > 0.f ? d[r] * w4.z : 0.f; z.w = h[r].w > 0.f ? d[r] * w4.w : 0.f;
+      if (vec) *reinterpret_cast<float4*>(dZ + o) = z;
+      else { const float* zp = &z.x; for (int q = 0; q < nv; ++q) dZ[o + q] = zp[q]; }
+      acc.x += d[r] * h[r].x; acc.y += d[r] * h[r].y; acc.z += d[r] * h[r].z; acc.w += d[r] * h[r].w;
+    }
+    float* out = a.part_dw[net] + (size_t)blockIdx.x * a.H + c0;
+    const float* ap = &acc.x;
+    for (int q = 0; q < nv; ++q) out[q] = ap[q];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------

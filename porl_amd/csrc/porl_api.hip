@@ -81,6 +81,7 @@ constexpr int NUM_CU = 256;
 constexpr int SK_MAX = 16;
 constexpr int NLL_ROWS_PER_BLOCK = 4;    // one row per wave
 constexpr int LN_ROWS_PER_BLOCK = 8;
+constexpr int HEAD_ROWS_PER_BLOCK = HEAD_ROWS;
 
 inline int64_t ru4(int64_t x) { return (x + 3) & ~int64_t(3); }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -129,6 +130,7 @@ struct Workspace {
   int64_t part_loss, part_min, part_dls;
   int64_t xhat_v[2][PORL_MAX_HIDDEN], rstd_v[2][PORL_MAX_HIDDEN];   // LayerNorm only
   int64_t ln_dg[2], ln_db[2], ln_dh[2];
+  int64_t head_part[2];                                              // relu_head_bwd partials
   int64_t total;
 };
 
@@ -213,7 +215,7 @@ int launch_reduce(ReduceArgs& r, hipStream_t s) {
   if (r.njobs == 0) return 0;
   long maxn = 0;
   for (int i = 0; i < r.njobs; ++i) maxn = std::max(maxn, r.job[i].n);
-  dim3 grid((unsigned)std::min<long>((maxn + 255) / 256, 512), r.njobs);
+  dim3 grid((unsigned)std::min<long>((maxn + 31) / 32, 2048), r.njobs);
   hipLaunchKernelGGL(multi_reduce_kernel, grid, dim3(256), 0, s, r);
   PORL_HIP(hipGetLastError());
   return 0;
@@ -330,6 +332,7 @@ int porl_iql_create(const porl_iql_cfg* c, porl_iql** out) {
   w.slab_b = take((int64_t)SK_MAX * ((int64_t)D * H + D + 8));
   const int nblk = cdiv(B, NLL_ROWS_PER_BLOCK);
   w.part_loss = take(nblk); w.part_min = take(nblk); w.part_dls = take((int64_t)nblk * D);
+  for (int i = 0; i < 2; ++i) w.head_part[i] = take((int64_t)cdiv(B, HEAD_ROWS_PER_BLOCK) * H);
   if (c->layer_norm) {
     const int nln = cdiv(B, LN_ROWS_PER_BLOCK);
     for (int i = 0; i < 2; ++i) {
@@ -559,31 +562,35 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
     PORL_HIP(hipGetLastError());
   }
 
-  // (output layer: db_L comes from the loss kernel, dW_L = dv^T H_{L-1} rides on the top wgrad's A loader)
-
-  // -- hidden layers, top down.  dZ of the top layer is never materialised: it is the rank-1 prologue
-  //    dv[b] * w_L[j] * 1[H_{L-1}[b,j] > 0] applied while staging H_{L-1}. ----------------------------
+  // (output layer: db_L comes from the loss kernel)
   ReduceArgs red{};
   if (LN) return value_backward_ln(h, hp, s);
+  // -- head + last ReLU backward: dZ_{L-1} = dv w_L^T . 1[H_{L-1} > 0], dW_L = dv^T H_{L-1} (partials) -----
+  {
+    const int nhb = cdiv(B, HEAD_ROWS_PER_BLOCK);
+    HeadBwdArgs a{};
+    for (int i = 0; i < 2; ++i) {
+      a.Hact[i] = W + ws.act_v[i][L - 1]; a.dv[i] = W + ws.dv[i]; a.w[i] = Pv + h->v[i].w[L];
+      a.dZ[i] = W + ws.dz_v[i][(L - 1) & 1]; a.part_dw[i] = W + ws.head_part[i];
+      add_reduce(red, Gv + h->v[i].w[L], W + ws.head_part[i], H, H, nhb);
+    }
+    a.B = B; a.H = H; a.ld = Hp;
+    hipLaunchKernelGGL(relu_head_bwd_kernel, dim3(nhb, 2), dim3(256), 0, s, a);
+    PORL_HIP(hipGetLastError());
+  }
   for (int l = L - 1; l >= 0; --l) {
-    const bool top = l == L - 1;
     const int Kin = l == 0 ? S : H;
     GemmGroup g{};
     for (int i = 0; i < 2; ++i) {
-      const float* dz = top ? W + ws.act_v[i][L - 1] : W + ws.dz_v[i][l & 1];
+      const float* dz = W + ws.dz_v[i][l & 1];
       const float* in = l == 0 ? W + ws.xs : W + ws.act_v[i][l - 1];
       const int ldin = l == 0 ? h->Sp : Hp;
       GemmProb p = make_prob(GEMM_TN, dz, Hp, in, ldin, Gv + h->v[i].w[l], Kin, H, Kin, B);
       p.colsum = Gv + h->v[i].b[l];
-      if (top) {
-        p.apro = APRO_RANK1_MASK; p.a_rowscale = W + ws.dv[i]; p.a_colscale = Pv + h->v[i].w[L];
-        p.rawdot = Gv + h->v[i].w[L];
-      }
       g.p[g.nprob++] = p;
       if (l > 0) {
         GemmProb q = make_prob(GEMM_NN, dz, Hp, Pv + h->v[i].w[l], Kin, W + ws.dz_v[i][(l - 1) & 1], Hp, B, Kin, H);
         q.mask = W + ws.act_v[i][l - 1]; q.ldmask = Hp;
-        if (top) { q.apro = APRO_RANK1_MASK; q.a_rowscale = W + ws.dv[i]; q.a_colscale = Pv + h->v[i].w[L]; }
         g.p[g.nprob++] = q;
       }
     }
@@ -601,11 +608,6 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
           g.p[i].splitk = sk; g.p[i].C = slabW; g.p[i].colsum = slabC;
           add_reduce(red, Gv + h->v[i].w[0], slabW, per, per, sk);
           add_reduce(red, Gv + h->v[i].b[0], slabC, perc, perc, sk);
-          if (g.p[i].rawdot) {   // single hidden layer: the head gradient is split the same way
-            float* slabR = slabC + (int64_t)SK_MAX * perc;
-            g.p[i].rawdot = slabR;
-            add_reduce(red, Gv + h->v[i].w[L], slabR, perc, perc, sk);
-          }
         }
       }
     }
