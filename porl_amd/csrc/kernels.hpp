@@ -257,9 +257,12 @@ __global__ __launch_bounds__(256) void policy_nll_kernel(const PolicyNllArgs a) 
 #pragma unroll
     for (int c = 0; c < NLL_MAX_COLS_PER_LANE; ++c) {
       const int j = lane + 64 * c;
-      if (c < ncl && j < a.D)
-        a.part_dls[(size_t)blockIdx.x * a.D + j] =
-            sh_dls[0][c * 64 + lane] + sh_dls[1][c * 64 + lane] + sh_dls[2][c * 64 + lane] + sh_dls[3][c * 64 + lane];
+      if (c < ncl && j < a.D) {
+        const float ls = a.log_std[j];          // clamp(log_std, -5, 2) passes no gradient outside its range
+        const float inside = (ls >= LOG_STD_MIN && ls <= LOG_STD_MAX) ? 1.f : 0.f;
+        a.part_dls[(size_t)blockIdx.x * a.D + j] = inside *
+            (sh_dls[0][c * 64 + lane] + sh_dls[1][c * 64 + lane] + sh_dls[2][c * 64 + lane] + sh_dls[3][c * 64 + lane]);
+      }
     }
     if (lane == 0) {
       a.part_loss[blockIdx.x] = sh_loss[0] + sh_loss[1] + sh_loss[2] + sh_loss[3];
@@ -340,8 +343,10 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
 struct ReduceJob {
   float* out; const float* slab; const float* bias;
   long n; long stride; int nslab; int ncols; int act;
+  int op;          // 0: sum of the slabs, 1: minimum
+  float scale;     // applied to the sum (1 = none)
 };
-struct ReduceArgs { int njobs; ReduceJob job[8]; };
+struct ReduceArgs { int njobs; ReduceJob job[12]; };
 
 // block = 32 outputs x 8 slab lanes: lane ty adds slabs ty, ty+8, ... (independent loads in flight), then the
 // 8 partial sums are combined in a fixed order through LDS — latency is nslab/8 loads deep, not nslab.
@@ -351,15 +356,19 @@ __global__ __launch_bounds__(256) void multi_reduce_kernel(const ReduceArgs a) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (long i0 = (long)blockIdx.x * 32; i0 < j.n; i0 += (long)gridDim.x * 32) {
     const long i = i0 + tx;
-    float s = 0.f;
+    float s = j.op ? INFINITY : 0.f;
     if (i < j.n)
-      for (int k = ty; k < j.nslab; k += 8) s += j.slab[(long)k * j.stride + i];
+      for (int k = ty; k < j.nslab; k += 8) {
+        const float x = j.slab[(long)k * j.stride + i];
+        s = j.op ? fminf(s, x) : s + x;
+      }
     sh[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && i < j.n) {
       float t = sh[0][tx];
 #pragma unroll
-      for (int q = 1; q < 8; ++q) t += sh[q][tx];
+      for (int q = 1; q < 8; ++q) t = j.op ? fminf(t, sh[q][tx]) : t + sh[q][tx];
+      t *= j.scale;
       if (j.bias) t += j.bias[i % j.ncols];
       if (j.act == 1) t = fmaxf(t, 0.f);
       else if (j.act == 2) t = tanhf(t);
@@ -498,51 +507,98 @@ __global__ void sample_indices_kernel(int64_t n, int batch, uint64_t seed, uint6
 // between f32 MFMAs is not free: a separate 16 MB pass is cheaper.)
 // ---------------------------------------------------------------------------------------------------
 struct HeadBwdArgs {
-  const float* Hact[2]; const float* dv[2]; const float* w[2];
+  const float* Hact[2]; const float* w[2];
   float* dZ[2]; float* part_dw[2];      // part_dw: [nblk][H]
-  int B, H, ld;
+  // fused TD-target / expectile head (agent/por.py:81-87): v = sum(parts) + b for the 4 nets
+  const float* hp_t[2]; const float* hp_v[2]; const float* b_t[2]; const float* b_v[2];
+  const float* rew; const float* term;
+  float* target_v; float* dv[2];
+  float* part_loss; float* part_db[2];  // [nblk] each: partial v_loss and partial sum of dv (= db_L)
+  int B, H, ld, parts;
+  float tau, discount, inv_batch;
 };
 constexpr int HEAD_ROWS = 16;            // rows per block; all 16 row loads of a thread are in flight together
 
 __global__ __launch_bounds__(256) void relu_head_bwd_kernel(const HeadBwdArgs a) {
+  __shared__ float sh_dv[2][HEAD_ROWS];
+  __shared__ float sh_loss[4];
   const int net = blockIdx.y;
   const float* __restrict__ Hm = a.Hact[net];
-  const float* __restrict__ dv = a.dv[net];
   float* __restrict__ dZ = a.dZ[net];
   const int row0 = blockIdx.x * HEAD_ROWS;
   const bool vec = (a.H & 3) == 0 && (a.ld & 3) == 0;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // -- loss head for this block's rows: wave w handles rows w, w+4, ...; lanes split the partial sums.
+  //    Both nets' blocks compute the same numbers (cheap); the net-0 block publishes them. ---------------
+  float loss = 0.f;
+  for (int r = wave; r < HEAD_ROWS; r += 4) {
+    const int b = row0 + r;
+    float t0 = 0.f, t1 = 0.f, v0 = 0.f, v1 = 0.f;
+    if (b < a.B)
+      for (int p = lane; p < a.parts; p += 64) {
+        const size_t o = (size_t)p * a.B + b;
+        t0 += a.hp_t[0][o]; t1 += a.hp_t[1][o]; v0 += a.hp_v[0][o]; v1 += a.hp_v[1][o];
+      }
+    t0 = wave_sum(t0); t1 = wave_sum(t1); v0 = wave_sum(v0); v1 = wave_sum(v1);
+    float d0 = 0.f, d1 = 0.f;
+    if (b < a.B) {
+      t0 += a.b_t[0][0]; t1 += a.b_t[1][0]; v0 += a.b_v[0][0]; v1 += a.b_v[1][0];
+      const float tgt = a.rew[b] + (1.f - a.term[b]) * a.discount * fminf(t0, t1);
+      const float u0 = tgt - v0, u1 = tgt - v1;
+      const float w0 = fabsf(a.tau - (u0 < 0.f ? 1.f : 0.f)), w1 = fabsf(a.tau - (u1 < 0.f ? 1.f : 0.f));
+      d0 = -w0 * u0 * a.inv_batch; d1 = -w1 * u1 * a.inv_batch;
+      loss += 0.5f * (w0 * u0 * u0 + w1 * u1 * u1);
+      if (net == 0 && lane == 0) { a.target_v[b] = tgt; a.dv[0][b] = d0; a.dv[1][b] = d1; }
+    }
+    if (lane == 0) { sh_dv[0][r] = d0; sh_dv[1][r] = d1; }
+  }
+  if (lane == 0) sh_loss[wave] = loss;
+  __syncthreads();
+  if (threadIdx.x == 0) {                     // fixed summation order
+    float dsm = 0.f;
+    for (int r = 0; r < HEAD_ROWS; ++r) dsm += sh_dv[net][r];
+    a.part_db[net][blockIdx.x] = dsm;
+    if (net == 0) a.part_loss[blockIdx.x] = sh_loss[0] + sh_loss[1] + sh_loss[2] + sh_loss[3];
+  }
   float d[HEAD_ROWS];
 #pragma unroll
-  for (int r = 0; r < HEAD_ROWS; ++r) d[r] = row0 + r < a.B ? dv[row0 + r] : 0.f;
-  for (int c0 = threadIdx.x * 4; c0 < a.H; c0 += 1024) {
-    float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f), acc = w4;
-    const int nv = min(4, a.H - c0);
-    if (vec) w4 = *reinterpret_cast<const float4*>(a.w[net] + c0);
-    else { float* wp = &w4.x; for (int q = 0; q < nv; ++q) wp[q] = a.w[net][c0 + q]; }
-    float4 h[HEAD_ROWS];
+  for (int r = 0; r < HEAD_ROWS; ++r) d[r] = sh_dv[net][r];
+  if (vec) {
+    // 16-byte path: a float4 of columns per thread and pass; the 16 row loads are issued back to back
+    for (int c0 = threadIdx.x * 4; c0 < a.H; c0 += 1024) {
+      const float4 w4 = *reinterpret_cast<const float4*>(a.w[net] + c0);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 h[HEAD_ROWS];
 #pragma unroll
-    for (int r = 0; r < HEAD_ROWS; ++r) {
-      h[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      const size_t o = (size_t)(row0 + r) * a.ld + c0;
-      if (row0 + r < a.B) {
-        if (vec) h[r] = *reinterpret_cast<const float4*>(Hm + o);
-        else { float* hp = &h[r].x; for (int q = 0; q < nv; ++q) hp[q] = Hm[o + q]; }
+      for (int r = 0; r < HEAD_ROWS; ++r) {
+        const int b = min(row0 + r, a.B - 1);                     // clamped: rows past B re-read the last row
+        h[r] = *reinterpret_cast<const float4*>(Hm + (size_t)b * a.ld + c0);
       }
-    }
 #pragma unroll
-    for (int r = 0; r < HEAD_ROWS; ++r) {
-      if (row0 + r >= a.B) continue;
-      const size_t o = (size_t)(row0 + r) * a.ld + c0;
-      float4 z;
-      z.x = h[r].x > 0.f ? d[r] * w4.x : 0.f; z.y = h[r].y > 0.f ? d[r] * w4.y : 0.f;
-      z.z = h[r].z > 0.f ? d[r] * w4.z : 0.f; z.w = h[r].w > 0.f ? d[r] * w4.w : 0.f;
-      if (vec) *reinterpret_cast<float4*>(dZ + o) = z;
-      else { const float* zp = &z.x; for (int q = 0; q < nv; ++q) dZ[o + q] = zp[q]; }
-      acc.x += d[r] * h[r].x; acc.y += d[r] * h[r].y; acc.z += d[r] * h[r].z; acc.w += d[r] * h[r].w;
+      for (int r = 0; r < HEAD_ROWS; ++r) {
+        const float dr = d[r];                                     // 0 for rows past B
+        float4 z;
+        z.x = h[r].x > 0.f ? dr * w4.x : 0.f; z.y = h[r].y > 0.f ? dr * w4.y : 0.f;
+        z.z = h[r].z > 0.f ? dr * w4.z : 0.f; z.w = h[r].w > 0.f ? dr * w4.w : 0.f;
+        if (row0 + r < a.B) *reinterpret_cast<float4*>(dZ + (size_t)(row0 + r) * a.ld + c0) = z;
+        acc.x += dr * h[r].x; acc.y += dr * h[r].y; acc.z += dr * h[r].z; acc.w += dr * h[r].w;
+      }
+      *reinterpret_cast<float4*>(a.part_dw[net] + (size_t)blockIdx.x * a.H + c0) = acc;
     }
-    float* out = a.part_dw[net] + (size_t)blockIdx.x * a.H + c0;
-    const float* ap = &acc.x;
-    for (int q = 0; q < nv; ++q) out[q] = ap[q];
+  } else {
+    // odd widths: one column per thread and pass
+    for (int c = threadIdx.x; c < a.H; c += 256) {
+      const float wc = a.w[net][c];
+      float acc = 0.f;
+      for (int r = 0; r < HEAD_ROWS; ++r) {
+        const int b = row0 + r;
+        if (b >= a.B) break;
+        const float hv = Hm[(size_t)b * a.ld + c];
+        dZ[(size_t)b * a.ld + c] = hv > 0.f ? d[r] * wc : 0.f;
+        acc += d[r] * hv;
+      }
+      a.part_dw[net][(size_t)blockIdx.x * a.H + c] = acc;
+    }
   }
 }
 

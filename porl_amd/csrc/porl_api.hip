@@ -130,7 +130,7 @@ struct Workspace {
   int64_t part_loss, part_min, part_dls;
   int64_t xhat_v[2][PORL_MAX_HIDDEN], rstd_v[2][PORL_MAX_HIDDEN];   // LayerNorm only
   int64_t ln_dg[2], ln_db[2], ln_dh[2];
-  int64_t head_part[2];                                              // relu_head_bwd partials
+  int64_t head_part[2], head_loss, head_db[2];                       // relu_head_bwd partials
   int64_t total;
 };
 
@@ -221,9 +221,11 @@ int launch_reduce(ReduceArgs& r, hipStream_t s) {
   return 0;
 }
 
-void add_reduce(ReduceArgs& r, float* out, const float* slab, long n, long stride, int nslab) {
+void add_reduce(ReduceArgs& r, float* out, const float* slab, long n, long stride, int nslab, int op = 0,
+                float scale = 1.f) {
   ReduceJob& j = r.job[r.njobs++];
   j.out = out; j.slab = slab; j.bias = nullptr; j.n = n; j.stride = stride; j.nslab = nslab; j.ncols = 1; j.act = 0;
+  j.op = op; j.scale = scale;
 }
 
 int check_ready(const porl_iql* h, bool need_batch) {
@@ -332,7 +334,8 @@ int porl_iql_create(const porl_iql_cfg* c, porl_iql** out) {
   w.slab_b = take((int64_t)SK_MAX * ((int64_t)D * H + D + 8));
   const int nblk = cdiv(B, NLL_ROWS_PER_BLOCK);
   w.part_loss = take(nblk); w.part_min = take(nblk); w.part_dls = take((int64_t)nblk * D);
-  for (int i = 0; i < 2; ++i) w.head_part[i] = take((int64_t)cdiv(B, HEAD_ROWS_PER_BLOCK) * H);
+  for (int i = 0; i < 2; ++i) { w.head_part[i] = take((int64_t)cdiv(B, HEAD_ROWS_PER_BLOCK) * H); w.head_db[i] = take(cdiv(B, HEAD_ROWS_PER_BLOCK)); }
+  w.head_loss = take(cdiv(B, HEAD_ROWS_PER_BLOCK));
   if (c->layer_norm) {
     const int nln = cdiv(B, LN_ROWS_PER_BLOCK);
     for (int i = 0; i < 2; ++i) {
@@ -547,8 +550,9 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
     PORL_TRY(fwd_hidden_layer(h, nets, 4, B, K, l == L - 1, &parts, s));
   }
 
-  // -- TD target, expectile loss, dL/dv -----------------------------------------------------------------
-  {
+  // -- TD target, expectile loss, dL/dv: with LayerNorm a kernel of its own; otherwise fused into the head
+  //    backward below --------------------------------------------------------------------------------------
+  if (LN) {
     ValueLossArgs a{};
     for (int i = 0; i < 2; ++i) {
       a.hp_t[i] = W + ws.hp_t[i]; a.hp_v[i] = W + ws.hp_v[i];
@@ -562,7 +566,6 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
     PORL_HIP(hipGetLastError());
   }
 
-  // (output layer: db_L comes from the loss kernel)
   ReduceArgs red{};
   if (LN) return value_backward_ln(h, hp, s);
   // -- head + last ReLU backward: dZ_{L-1} = dv w_L^T . 1[H_{L-1} > 0], dW_L = dv^T H_{L-1} (partials) -----
@@ -570,11 +573,18 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
     const int nhb = cdiv(B, HEAD_ROWS_PER_BLOCK);
     HeadBwdArgs a{};
     for (int i = 0; i < 2; ++i) {
-      a.Hact[i] = W + ws.act_v[i][L - 1]; a.dv[i] = W + ws.dv[i]; a.w[i] = Pv + h->v[i].w[L];
+      a.Hact[i] = W + ws.act_v[i][L - 1]; a.w[i] = Pv + h->v[i].w[L];
       a.dZ[i] = W + ws.dz_v[i][(L - 1) & 1]; a.part_dw[i] = W + ws.head_part[i];
+      a.hp_t[i] = W + ws.hp_t[i]; a.hp_v[i] = W + ws.hp_v[i];
+      a.b_t[i] = Pt + h->v[i].b[L]; a.b_v[i] = Pv + h->v[i].b[L];
+      a.dv[i] = W + ws.dv[i]; a.part_db[i] = W + ws.head_db[i];
       add_reduce(red, Gv + h->v[i].w[L], W + ws.head_part[i], H, H, nhb);
+      add_reduce(red, Gv + h->v[i].b[L], W + ws.head_db[i], 1, 1, nhb);
     }
-    a.B = B; a.H = H; a.ld = Hp;
+    a.rew = W + ws.rew; a.term = W + ws.term; a.target_v = W + ws.target_v; a.part_loss = W + ws.head_loss;
+    add_reduce(red, h->buf.stats, W + ws.head_loss, 1, 1, nhb, 0, hp->inv_batch);     // stats[0] = v_loss
+    a.B = B; a.H = H; a.ld = Hp; a.parts = parts;
+    a.tau = hp->tau; a.discount = hp->discount; a.inv_batch = hp->inv_batch;
     hipLaunchKernelGGL(relu_head_bwd_kernel, dim3(nhb, 2), dim3(256), 0, s, a);
     PORL_HIP(hipGetLastError());
   }
@@ -727,13 +737,14 @@ int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream
     a.alpha = hp->alpha; a.inv_batch = hp->inv_batch; a.rows_per_block = NLL_ROWS_PER_BLOCK;
     hipLaunchKernelGGL(policy_nll_kernel, dim3(nblk), dim3(256), 0, s, a);
     PORL_HIP(hipGetLastError());
-    hipLaunchKernelGGL(policy_nll_finalize_kernel, dim3(cdiv(D, 4) + 1), dim3(256), 0, s, W + ws.part_loss, W + ws.part_min,
-                       W + ws.part_dls, nblk, D, Pp + h->logstd_off, Gp + h->logstd_off, h->buf.stats);
-    PORL_HIP(hipGetLastError());
   }
 
   // -- backward ---------------------------------------------------------------------------------------
   ReduceArgs red{};
+  // the NLL kernel's per-block partials are combined by the step's final reduce launch
+  add_reduce(red, Gp + h->logstd_off, W + ws.part_dls, D, D, nblk);            // d/dlog_std (already clamp-masked)
+  add_reduce(red, h->buf.stats + 1, W + ws.part_loss, 1, 1, nblk);            // stats[1] = g_loss
+  add_reduce(red, h->buf.stats + 2, W + ws.part_min, 1, 1, nblk, /*min*/ 1);  // stats[2] = min NLL
   {
     // output layer: dW_L = dmu^T H_{L-1} (D x H, skinny M), and dZ_{L-1} = (dmu W_L) . 1[H_{L-1} > 0]
     GemmGroup g{};
