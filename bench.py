@@ -176,8 +176,14 @@ def main():
             avg_ms = dom["total_ms"] / dom["launches"]
             flops_per_launch = dom["flops"] / dom["launches"]
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/), if present
+            try:
+                tj = json.load(open(os.path.join(REPO, "profiles", "r01_hbm_traffic.json")))
+                traffic = tj["kernels"][dom["name"]]["hbm_bytes_per_launch"]
+            except Exception:
+                pass
             roof = dict(bound="mfma", kernel=dom["name"], achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=None,
+                        frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=traffic,
                         avg_launch_us=avg_ms * 1e3, launches=dom["launches"],
                         flop_per_launch=flops_per_launch,
                         all_kernels_ms_per_step={p["name"]: p["total_ms"] / a.steps for p in prof if p["launches"]})

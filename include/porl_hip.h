@@ -237,6 +237,13 @@ int porl_gather_rows(const float* rows, int64_t row_stride, const int64_t* idx, 
 int porl_sample_indices(int64_t n_rows, int32_t batch, uint64_t seed, uint64_t step, int64_t base,
                         int64_t* out, void* stream);
 
+/* state2costmap (util/costmap.py:7-64; called by FasterNet.forward_cls, agent/fasternet.py:431):
+ * (batch, n_ang + 2) lidar ranges + relative goal (x, y), row stride state_rs -> out (batch, 3, n_ang, n_dist)
+ * contiguous.  The reference uses n_ang = 360, n_dist = 256.  Like the reference, entries > 8 of `state` are
+ * zeroed in place. */
+int porl_state2costmap(float* state, int64_t state_rs, int32_t batch, int32_t n_ang, int32_t n_dist,
+                       float* out, void* stream);
+
 /* Experiment knobs (placement only, never results).  "gemm_lds_pad": extra dynamic LDS bytes per GEMM
  * block, limiting how many blocks share a CU. */
 int porl_tune_set(const char* key, int value);

@@ -13,6 +13,7 @@ What is pinned:
             upstream; gymnasium/ipdb/tensorboard are stubbed (not installed).
   replay_*: ReplayBuffer.push/sample index streams under np.random.seed
             (/root/reference/buffer/replay_buffer.py:33-75)
+  costmap_*: state2costmap (/root/reference/util/costmap.py:7-64)
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py </dev/null
 """
@@ -255,6 +256,26 @@ def gen_replay(name, N, cap, S, B, K, seed_np=11):
     print(f"{name}: size={len(rb)} pos={rb.position}")
 
 
+def gen_costmap(name, B=24, seed=13):
+    """state2costmap (util/costmap.py:7-64): inputs, the in-place-modified state, and the nonzero pixels."""
+    from util.costmap import state2costmap
+    rng = np.random.default_rng(seed)
+    st = np.empty((B, 362), dtype=np.float32)
+    st[:, :360] = rng.uniform(0.15, 3.9, size=(B, 360))
+    st[:, 360:] = rng.uniform(-3.0, 3.0, size=(B, 2))
+    st[0, 5] = 9.5; st[0, 200] = 8.5; st[1, 17] = 0.0; st[2, 360:] = (0.001, 0.0)      # > 8 -> 0; bin 0; dist bin 0 (wraps)
+    st[3, 360:] = (-2.0, 1e-4); st[4, 360:] = (-2.0, -1e-4); st[5, 360:] = (0.0, 3.9)  # angle clamp edges, far goal
+    st[6, 360:] = (20.0, 20.0)                                                          # goal coords > 8 are zeroed too
+    st[7, :360] = 3.99
+    x = torch.from_numpy(st.copy())
+    out = state2costmap(x).contiguous().numpy()
+    nz = np.argwhere(out != 0).astype(np.int32)
+    assert np.all(out[out != 0] == 1.0)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), state_in=st, state_after=x.numpy(), nonzero=nz,
+                        shape=np.array(out.shape))
+    print(f"{name}: {nz.shape[0]} nonzero pixels")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -277,6 +298,8 @@ def main():
     gen_cql("cql_s8_a4_b256", S=8, A=4, B=256, K=4, N=1000, seed_model=1, seed_np=9)
     # Replay buffer
     gen_replay("replay_ring", N=700, cap=512, S=8, B=64, K=3)
+    # costmap rasteriser
+    gen_costmap("costmap_b24")
 
 
 if __name__ == "__main__":

@@ -833,6 +833,55 @@ __global__ __launch_bounds__(256) void cql_penalty_kernel(const float* __restric
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// state2costmap (util/costmap.py:7-64): (B, n_ang + 2) lidar ranges + relative goal -> (B, 3, n_ang, n_dist)
+// polar occupancy image.  One block per (angle row, sample), one thread per distance bin; the image is
+// written directly in channel-major order (the reference builds (B, n_ang, n_dist, 3) and permutes).
+//   * values > 8 count as 0 everywhere and are zeroed IN PLACE like the reference does (:17)
+//   * channel 0: one-hot of int(range / d_inc) per beam, beams rolled by n_ang/2, bin 0 cleared
+//   * all channels: 3-pixel cross at the goal's (angle bin, distance bin); index -1 wraps to the last bin
+//     exactly as the reference's advanced indexing does (dist bin 0 lights bin n_dist-1)
+// Ranges that would index past n_dist-1 make the reference raise; here they are dropped.
+// ---------------------------------------------------------------------------------------------------
+__global__ void costmap_kernel(float* __restrict__ state, long state_stride, int n_ang, int n_dist,
+                               float dist_inc, float ang_inc, float deg_min, float deg_max, float dist_max,
+                               float* __restrict__ out) {
+  const int r = blockIdx.x, b = blockIdx.y;
+  float* st = state + (long)b * state_stride;
+  auto rd = [&](int i) { const float v = st[i]; return v > 8.f ? 0.f : v; };
+  const int src = (r - n_ang / 2 + n_ang) % n_ang;              // torch.roll(idx, n_ang/2, 1)
+  const long beam_bin = (long)(rd(src) / dist_inc);             // .to(torch.long): truncation
+  const float gx = rd(n_ang), gy = rd(n_ang + 1);
+  float deg = atan2f(gy, gx);
+  deg = fminf(fmaxf(deg, deg_min), deg_max);
+  const long deg_bin = (long)((deg + 3.14159265358979323846f) / ang_inc);
+  const float cd = fminf(sqrtf(gx * gx + gy * gy), dist_max);
+  const long dist_bin = (long)(cd / dist_inc);
+  auto wrap = [](long i, int n) { return i < 0 ? i + n : i; };  // python negative-index semantics
+  const bool row_is_deg = r == wrap(deg_bin, n_ang);
+  const bool row_near_deg = row_is_deg || r == wrap(deg_bin - 1, n_ang) || r == wrap(deg_bin + 1, n_ang);
+  const size_t plane = (size_t)n_ang * n_dist;
+  float* o = out + (size_t)b * 3 * plane + (size_t)r * n_dist;
+  for (int c = threadIdx.x; c < n_dist; c += blockDim.x) {
+    const bool cross = (row_is_deg && (c == wrap(dist_bin - 1, n_dist) || c == wrap(dist_bin, n_dist) ||
+                                       c == wrap(dist_bin + 1, n_dist))) ||
+                       (row_near_deg && c == wrap(dist_bin, n_dist));
+    const bool beam = c != 0 && (long)c == beam_bin;
+    o[c] = (beam || cross) ? 1.f : 0.f;
+    o[plane + c] = cross ? 1.f : 0.f;
+    o[2 * plane + c] = cross ? 1.f : 0.f;
+  }
+}
+
+// the in-place side effect: state[state > 8] = 0 (runs after costmap_kernel on the same stream)
+__global__ void clamp_gt8_kernel(float* __restrict__ state, long state_stride, int cols, int rows) {
+  const long n = (long)rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float* p = state + (i / cols) * state_stride + (i % cols);
+    if (*p > 8.f) *p = 0.f;
+  }
+}
+
 // int64 copy with stride (actions hand-over)
 __global__ void pack_i64_kernel(const int64_t* __restrict__ src, long stride, int n, int64_t* __restrict__ dst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -946,6 +946,27 @@ int porl_tune_set(const char* key, int value) {
   PORL_FAIL(PORL_ERR_INVALID, "unknown tuning key '%s'", key);
 }
 
+int porl_state2costmap(float* state, int64_t state_rs, int32_t batch, int32_t n_ang, int32_t n_dist, float* out,
+                        void* stream) {
+  if (!state || !out || batch < 1 || n_ang < 4 || n_dist < 4) PORL_FAIL(PORL_ERR_INVALID, "bad costmap arguments");
+  if (batch > 65535) PORL_FAIL(PORL_ERR_INVALID, "batch > 65535");
+  hipStream_t s = (hipStream_t)stream;
+  // constants exactly as util/costmap.py:19-20,34,45 forms them (python doubles rounded to fp32 at the tensor op)
+  const double pi = 3.14159265358979323846;
+  const float dist_inc = (float)((4.0 + 1e-4) / n_dist);
+  const float ang_inc = (float)((2.0 * pi + 1e-4) / n_ang);
+  const float deg_min = (float)(-pi + (2.0 * pi + 2e-4) / n_ang), deg_max = (float)(pi - (2.0 * pi + 2e-4) / n_ang);
+  const float dist_max = (float)(4.0 - 4.0 / n_dist);
+  hipLaunchKernelGGL(costmap_kernel, dim3(n_ang, batch), dim3(std::min(256, n_dist)), 0, s, state, (long)state_rs, n_ang,
+                     n_dist, dist_inc, ang_inc, deg_min, deg_max, dist_max, out);
+  PORL_HIP(hipGetLastError());
+  const long n = (long)batch * (n_ang + 2);
+  hipLaunchKernelGGL(clamp_gt8_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024)), dim3(256), 0, s, state,
+                     (long)state_rs, n_ang + 2, batch);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
 int porl_prof_enable(int on) {
   g_prof.on = on != 0;
   g_prof.recs.clear();
