@@ -90,8 +90,52 @@ def cpu_baseline(budget_s=15.0):
                        f"{best_t} threads = best of 8..{max_threads}) in {el:.1f} s")
 
 
+def bench_cql(a):
+    """Secondary workload (BASELINE config 3): CQL(H) learn() at B=4096, S=60, A=10, Q-net 64-128-64, 100 k-row
+    buffer resident on the device, indices drawn on the device.  Not the headline metric."""
+    import numpy as np
+    import torch
+    from porl_amd.train.cql_trainer import CQLTrainer
+    from porl_amd.util.synth import make_discrete_transitions
+    from oracle.por_oracle import CqlOracle
+    dev = torch.device("cuda", 0)
+    Sq, Aq, Bq, Nq = 60, 10, 4096, 100_000
+    torch.manual_seed(0)
+    t = CQLTrainer(state_size=Sq, action_size=Aq, gamma=0.99, device=dev, batch_size=Bq)
+    st, ac, rw, ns, dn = make_discrete_transitions(Nq, Sq, Aq, seed=0)
+    rb = t.replay_buffer
+    rb.states[:Nq], rb.actions[:Nq], rb.rewards[:Nq], rb.next_states[:Nq], rb.dones[:Nq] = st, ac, rw, ns, dn
+    rb.size, rb.position = Nq, 0
+    t.async_losses = True
+    for i in range(a.warmup):
+        t.learn_device_sampled()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        t.learn_device_sampled()
+        if i % 10 == 0:
+            t.sync_target()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    o = CqlOracle({k: v.detach().cpu().numpy() for k, v in t.q_network.state_dict().items()}, Aq)
+    rng = np.random.default_rng(0)
+    n, c0 = 0, time.perf_counter()
+    while time.perf_counter() - c0 < 5.0:
+        idx = rng.choice(Nq, Bq, replace=False)
+        o.learn(st[idx], ac[idx], rw[idx], ns[idx], dn[idx])
+        n += 1
+    cpu = n / (time.perf_counter() - c0)
+    print(json.dumps({"metric": "gradient-steps/sec (CQL learn, batch=4096)", "value": a.steps / el,
+                      "unit": "gradient-steps/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+                      "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "CQL S=60 A=10 B=4096 Q-net 64-128-64, 100k-row device-resident buffer"},
+                      "cpu_baseline": {"value": cpu, "unit": "gradient-steps/sec", "kind": "port",
+                                       "sample": f"{n} oracle learn() calls incl. numpy sampling in 5 s"}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="por", choices=["por", "cql"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
@@ -99,6 +143,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
+    if a.workload == "cql":
+        return bench_cql(a)
 
     import numpy as np
     import torch

@@ -86,8 +86,12 @@ class ReplayBuffer:
         if self.device.type != "cuda":
             raise E.N.NativeError("ReplayBuffer.sample gathers on a HIP device (device='cuda'); no CPU path")
         self._sync_mirror()
-        m = self._mirror
         idx = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int64)).to(self.device, non_blocking=True)
+        return self.gather_device(idx)
+
+    def gather_device(self, idx):
+        """The five minibatch tensors for int64 indices that already live on the device."""
+        m = self._mirror
         B = idx.numel()
         states = E.gather_rows(m["states"], idx).view(B, *self.state_shape)
         next_states = E.gather_rows(m["next_states"], idx).view(B, *self.state_shape)

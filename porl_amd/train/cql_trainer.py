@@ -209,6 +209,19 @@ class CQLTrainer:
     def learn(self):
         return self.learn_on(*self.replay_buffer.sample(self.batch_size))
 
+    def learn_device_sampled(self, seed=0):
+        """Extension (not in the reference): `learn()` with the B distinct indices drawn on the device (keyed
+        permutation) instead of numpy's O(N) host permutation — no host work, no host->device copies."""
+        from .. import engine as E
+        rb = self.replay_buffer
+        if self.batch_size > rb.size:
+            raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+        rb._sync_mirror()
+        self._draws = getattr(self, "_draws", 0)
+        idx = E.sample_indices(rb.size, self.batch_size, seed, self._draws, device=self.device)
+        self._draws += 1
+        return self.learn_on(*rb.gather_device(idx))
+
     def compute_cql_penalty(self, states, actions):
         return self._engine.penalty(states, actions)
 
