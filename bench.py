@@ -198,6 +198,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         one_step(a.warmup + i)
+    agent.flush()                                              # a deferred policy step belongs to the timed work
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

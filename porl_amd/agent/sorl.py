@@ -49,6 +49,7 @@ class SORL(IqlAgentBase):
 
     def select_action(agent, observations):
         """Mean action as a numpy array (reference sorl.py:71-76)."""
+        agent.flush()
         return agent.policy(observations).mean.cpu().numpy()
 
     def update(agent, observations, actions, rewards, next_observations, terminals):

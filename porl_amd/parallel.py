@@ -36,6 +36,14 @@ class GradExchange:
             d.all_reduce(flat, op=d.ReduceOp.SUM, group=self.group)
         return flat
 
+    def allreduce_sum_async(self, flat: torch.Tensor):
+        """Start the SUM all-reduce and return its work handle (None when there is nothing to exchange).  The
+        collective runs on the backend's own stream; `handle.wait()` orders the current stream behind it."""
+        d = _dist()
+        if d and d.get_world_size(self.group) > 1:
+            return d.all_reduce(flat, op=d.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
+
     def allreduce_stats_(self, stats: torch.Tensor):
         """stats[0:2] = (v_loss, g_loss) shares -> SUM; stats[2] = min NLL -> MIN."""
         d = _dist()

@@ -32,7 +32,7 @@ def _agent(B):
                1000, 0.9, 10.0, device=torch.device("cuda"))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, async_mode=False):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
@@ -40,30 +40,36 @@ def _worker(rank, world, port, out_dir):
     from porl_amd.util.synth import split_rows
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     agent = _agent(BL)
+    agent.async_losses = async_mode                          # async: policy exchange overlapped, applied lazily
     rows = torch.from_numpy(_rows()).cuda()
     losses = []
     for k in range(STEPS):
         glob = rows[k * world * BL:(k + 1) * world * BL]
         local = glob[rank * BL:(rank + 1) * BL]              # this rank's shard of the global minibatch
         s, r, sp, d, _ = split_rows(local, S, 2)
-        losses.append(agent.por_residual_update(s, sp, r, d))
-    if rank == 0:
+        out = agent.por_residual_update(s, sp, r, d)
+        losses.append(tuple(out[:2].tolist()) if async_mode else out)
+    if async_mode:
+        assert agent._deferred is not None                   # the last policy step is still pending ...
+    if rank == 0:                                            # ... and state_dict() completes it
         np.savez(os.path.join(out_dir, "dp.npz"), losses=np.array(losses),
                  **{k: v.cpu().numpy() for k, v in agent.state_dict().items()})
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_update_equals_global_batch_update(tmp_path):
+@pytest.mark.parametrize("async_mode", [False, True])
+def test_two_rank_update_equals_global_batch_update(tmp_path, async_mode):
     from porl_amd.util.synth import split_rows
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), async_mode), nprocs=world, join=True)
     got = np.load(tmp_path / "dp.npz")
     agent = _agent(world * BL)
     rows = torch.from_numpy(_rows()).cuda()
     for k in range(STEPS):
         s, r, sp, d, _ = split_rows(rows[k * world * BL:(k + 1) * world * BL], S, 2)
         loss = agent.por_residual_update(s, sp, r, d)
-        np.testing.assert_allclose(got["losses"][k], loss, rtol=2e-6)
+        if not async_mode:                                   # async mode reports per-rank loss shares
+            np.testing.assert_allclose(got["losses"][k], loss, rtol=2e-6)
     for k, v in agent.state_dict().items():
         np.testing.assert_allclose(got[k], v.cpu().numpy(), atol=2e-6, err_msg=k)
