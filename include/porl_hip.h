@@ -244,6 +244,50 @@ int porl_sample_indices(int64_t n_rows, int32_t batch, uint64_t seed, uint64_t s
 int porl_state2costmap(float* state, int64_t state_rs, int32_t batch, int32_t n_ang, int32_t n_dist,
                        float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Costmap encoder engine: FasterNet.forward_cls (agent/fasternet.py:428-438) as built by
+ * sorl_train.py:29 `FasterNet(3, args.feature_dim)` — state2costmap, PatchEmbed 4x4s4 + BN (:234-246),
+ * depth0 MLPBlocks (:141-194, Partial_conv3 :110-138), PatchMerging 2x2s2 + BN (:249-261), depth1
+ * MLPBlocks, AdaptiveAvgPool2d(1) + 1x1 conv + ReLU (:367-371), Linear head (:372).  Forward only: the
+ * reference keeps the backbone out of every optimizer (agent/sorl.py:58-64), so its backward never
+ * changes a result.  BatchNorm follows nn.BatchNorm2d: batch statistics + running-stat update when
+ * `training`, running statistics otherwise.
+ * --------------------------------------------------------------------------------------------- */
+#define PORL_ENC_MAX_BLOCKS 8
+typedef struct porl_enc porl_enc;
+typedef struct porl_enc_cfg {
+  int32_t n_ang, n_dist;      /* costmap image height x width (reference: 360 x 256) */
+  int32_t embed_dim;          /* 96 */
+  int32_t depth0, depth1;     /* MLPBlocks per stage (reference depths=(1,2)) */
+  int32_t n_div;              /* PConv acts on embed_dim/n_div channels (4) */
+  int32_t feature_dim;        /* width of the pre-head 1x1 conv (1280) */
+  int32_t num_classes;        /* output features per sample (sorl_train.py:29 -> 256) */
+  int32_t max_batch;
+  float mlp_ratio;            /* 2.0 */
+  float bn_eps, bn_momentum;  /* nn.BatchNorm2d defaults 1e-5, 0.1 */
+} porl_enc_cfg;
+
+int porl_enc_create(const porl_enc_cfg* cfg, porl_enc** out);
+void porl_enc_destroy(porl_enc* h);
+int64_t porl_enc_param_floats(const porl_enc* h);      /* flat parameter buffer, state_dict order + layouts */
+int64_t porl_enc_stat_floats(const porl_enc* h);       /* BatchNorm running_mean / running_var buffer */
+int64_t porl_enc_workspace_floats(const porl_enc* h);
+int32_t porl_enc_tensors(const porl_enc* h);
+int32_t porl_enc_norms(const porl_enc* h);
+int32_t porl_enc_blocks(const porl_enc* h);            /* MLPBlocks = rows of drop_scale */
+/* name = the reference's state_dict key ("stages.0.blocks.0.mlp.0.weight", ...) */
+int porl_enc_tensor_info(const porl_enc* h, int32_t index, int64_t* offset, int64_t* numel, char* name,
+                         int32_t name_len);
+/* name = module prefix ("patch_embed.norm"); offsets into the stat buffer */
+int porl_enc_norm_info(const porl_enc* h, int32_t index, int64_t* mean_offset, int64_t* var_offset,
+                       int32_t* channels, char* name, int32_t name_len);
+int porl_enc_bind(porl_enc* h, float* params, float* bn_stats, float* workspace);
+/* state (batch, n_ang + 2) row stride state_rs, entries > 8 zeroed in place like the reference
+ * (util/costmap.py:17); drop_scale (blocks, batch) = DropPath keep mask / keep_prob per MLPBlock and
+ * sample (fasternet.py:76-93) or NULL for none; features (batch, num_classes), row stride feat_rs. */
+int porl_enc_forward(porl_enc* h, float* state, int64_t state_rs, int32_t batch, int32_t training,
+                     const float* drop_scale, float* features, int64_t feat_rs, void* stream);
+
 /* Experiment knobs (placement only, never results).  "gemm_lds_pad": extra dynamic LDS bytes per GEMM
  * block, limiting how many blocks share a CU. */
 int porl_tune_set(const char* key, int value);

@@ -14,6 +14,9 @@ What is pinned:
   replay_*: ReplayBuffer.push/sample index streams under np.random.seed
             (/root/reference/buffer/replay_buffer.py:33-75)
   costmap_*: state2costmap (/root/reference/util/costmap.py:7-64)
+  fasternet_*: FasterNet(3, 256).forward_cls (/root/reference/agent/fasternet.py:428-438) in eval mode and in
+            train mode (batch-stat BatchNorm, running-stat update, DropPath masks replayed from the seed)
+  sorl_enc_*: SORL.update with the FasterNet backbone (/root/reference/agent/sorl.py:78-128)
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py </dev/null
 """
@@ -276,6 +279,132 @@ def gen_costmap(name, B=24, seed=13):
     print(f"{name}: {nz.shape[0]} nonzero pixels")
 
 
+def fasternet_states(B, seed):
+    rng = np.random.default_rng(seed)
+    st = np.empty((B, 362), dtype=np.float32)
+    st[:, :360] = rng.uniform(0.15, 3.9, size=(B, 360))
+    st[:, 360:] = rng.uniform(-3.0, 3.0, size=(B, 2))
+    return st
+
+
+def replay_drop_scale(seed, B, probs, calls):
+    """The factors drop_path (fasternet.py:86-93) draws during `calls` forwards after torch.manual_seed(seed):
+    one bernoulli_(keep) of shape (B,1,1,1) per block with drop_prob > 0, nothing else touches the generator."""
+    torch.manual_seed(seed)
+    out = []
+    for _ in range(calls):
+        rows = []
+        for p in probs:
+            if p > 0:
+                rows.append((torch.empty(B, 1, 1, 1).bernoulli_(1 - p) / (1 - p)).view(B).numpy().copy())
+            else:
+                rows.append(np.ones(B, dtype=np.float32))
+        out.append(np.stack(rows))
+    return out
+
+
+def gen_fasternet(name, B=5, seed_model=0, seed_data=21):
+    """Encoder forward: weights are NOT stored (4 MB of noise) — the drop-in's constructor reproduces them from
+    seed_model and the fixture pins them by per-tensor checksums; stored are states, features and BatchNorm
+    statistics, plus small taps of intermediate activations that pin the oracle stage by stage."""
+    from agent.fasternet import FasterNet
+    torch.manual_seed(seed_model)
+    m = FasterNet(3, 256)
+    sd0 = sd_np(m)
+    out = {"seed_model": np.int64(seed_model), "B": np.int64(B)}
+    for i, (k, v) in enumerate(sd0.items()):
+        if v.ndim:
+            out["wsum." + k] = checksum(v, i)
+    st = fasternet_states(B, seed_data)
+    st2 = fasternet_states(B, seed_data + 1)
+    out["states"], out["states2"] = st, st2
+    probs = [float(x) for x in torch.linspace(0, 0.1, 3)]
+    out["drop_probs"] = np.array(probs)
+
+    taps = {}
+    hooks = []
+    for key, mod in (("patch_embed", m.patch_embed), ("stages.0", m.stages[0]), ("stages.1", m.stages[1]),
+                     ("stages.2", m.stages[2]), ("avgpool_pre_head", m.avgpool_pre_head)):
+        hooks.append(mod.register_forward_hook(lambda _m, _i, o, key=key: taps.__setitem__(key, o.detach().numpy().copy())))
+    m.eval()
+    with torch.no_grad():
+        out["feat_eval"] = m(torch.from_numpy(st.copy())).numpy().copy()
+    for k, v in taps.items():
+        v = v.reshape(v.shape[0], v.shape[1], -1) if v.ndim == 4 else v
+        out["tap_eval." + k] = np.concatenate([[v.astype(np.float64).sum(), np.abs(v.astype(np.float64)).sum()],
+                                               v[:, :6].astype(np.float64).reshape(v.shape[0], -1)[:, :24].ravel()])
+    for h in hooks:
+        h.remove()
+
+    # train mode: two consecutive forwards (running stats chain, generator keeps advancing)
+    m.train()
+    seed_fwd = None
+    for cand in range(100, 200):
+        ds = replay_drop_scale(cand, B, probs, 2)
+        if all((d == 0).any() for d in ds):
+            seed_fwd = cand
+            break
+    assert seed_fwd is not None
+    out["seed_fwd"] = np.int64(seed_fwd)
+    out["drop_scale1"], out["drop_scale2"] = ds
+    torch.manual_seed(seed_fwd)
+    with torch.no_grad():
+        out["feat_train1"] = m(torch.from_numpy(st.copy())).numpy().copy()
+        out["feat_train2"] = m(torch.from_numpy(st2.copy())).numpy().copy()
+    for k, v in sd_np(m).items():
+        if "running_" in k or "num_batches" in k:
+            out["stat_after." + k] = v
+    # eval again with the updated running statistics
+    m.eval()
+    with torch.no_grad():
+        out["feat_eval_after"] = m(torch.from_numpy(st.copy())).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: seed_fwd={seed_fwd} |feat_eval|max={np.abs(out['feat_eval']).max():.4g} "
+          f"|feat_train1|max={np.abs(out['feat_train1']).max():.4g}")
+
+
+def gen_sorl_enc(name, B=6, K=3, H=64, L=2, A=2, F=256, seed_model=0, seed_data=31, seed_fwd=77, alpha=3.0, tau=0.9):
+    """SORL.update with backbone=FasterNet(3, F) (sorl_train.py:29-33): K joint updates on (B, 362) states."""
+    from agent.fasternet import FasterNet
+    from agent.sorl import SORL
+    torch.manual_seed(seed_model)
+    backbone = FasterNet(3, F)
+    args = SimpleNamespace(state_size=362, feature_dim=F, hidden_dim=H, n_hidden=L, layer_norm=False, action_size=A)
+    agent = SORL(args, max_steps=50, tau=tau, alpha=alpha, backbone=backbone)
+    out = {"seed_model": np.int64(seed_model), "seed_fwd": np.int64(seed_fwd), "meta": np.array([B, K, H, L, A, F]),
+           "alpha": np.float64(alpha), "tau": np.float64(tau)}
+    sd0 = sd_np(agent)
+    for i, (k, v) in enumerate(sd0.items()):
+        if v.ndim and k.startswith("backbone."):
+            out["wsum." + k] = checksum(v, i)
+        elif not k.startswith("backbone."):
+            out["init." + k] = v
+    rng = np.random.default_rng(seed_data)
+    probs = [float(x) for x in torch.linspace(0, 0.1, 3)]
+    ds = replay_drop_scale(seed_fwd, B, probs, 2 * K)
+    torch.manual_seed(seed_fwd)
+    losses = []
+    for k in range(K):
+        s, s2 = fasternet_states(B, seed_data + 10 * k), fasternet_states(B, seed_data + 10 * k + 1)
+        a = rng.uniform(-1, 1, size=(B, A)).astype(np.float32)
+        r = rng.normal(size=B).astype(np.float32)
+        d = (rng.uniform(size=B) < 0.2).astype(np.float32)
+        out[f"s{k}"], out[f"s2{k}"], out[f"a{k}"], out[f"r{k}"], out[f"d{k}"] = s, s2, a, r, d
+        out[f"drop_s{k}"], out[f"drop_s2{k}"] = ds[2 * k], ds[2 * k + 1]
+        vl, gl = agent.update(torch.from_numpy(s.copy()), torch.from_numpy(a), torch.from_numpy(r),
+                              torch.from_numpy(s2.copy()), torch.from_numpy(d))
+        losses.append((vl, gl))
+    out["losses"] = np.array(losses, dtype=np.float64)
+    for k, v in sd_np(agent).items():
+        if k.startswith("backbone."):
+            if "running_" in k or "num_batches" in k:
+                out["final." + k] = v
+        else:
+            out["final." + k] = v
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: losses={losses}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -300,6 +429,9 @@ def main():
     gen_replay("replay_ring", N=700, cap=512, S=8, B=64, K=3)
     # costmap rasteriser
     gen_costmap("costmap_b24")
+    # FasterNet costmap encoder (config 5) and SORL with it as backbone
+    gen_fasternet("fasternet_b5", B=5)
+    gen_sorl_enc("sorl_enc_b6", B=6, K=3)
 
 
 if __name__ == "__main__":

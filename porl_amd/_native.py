@@ -27,6 +27,9 @@ SYMBOLS = [
     "porl_qnet_tensor_info", "porl_qnet_workspace_floats", "porl_qnet_bind", "porl_qnet_load_batch",
     "porl_qnet_cql_backward", "porl_qnet_apply", "porl_qnet_learn", "porl_qnet_sync_target",
     "porl_qnet_forward", "porl_qnet_penalty",
+    "porl_enc_create", "porl_enc_destroy", "porl_enc_param_floats", "porl_enc_stat_floats",
+    "porl_enc_workspace_floats", "porl_enc_tensors", "porl_enc_norms", "porl_enc_blocks",
+    "porl_enc_tensor_info", "porl_enc_norm_info", "porl_enc_bind", "porl_enc_forward",
 ]
 
 
@@ -61,6 +64,12 @@ class QnetBuffers(C.Structure):
 class QnetHyper(C.Structure):
     _fields_ = [("gamma", C.c_float), ("alpha", C.c_float), ("inv_batch", C.c_float), ("step", C.c_int32),
                 ("lr", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
+
+
+class EncCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_ang", "n_dist", "embed_dim", "depth0", "depth1", "n_div",
+                                         "feature_dim", "num_classes", "max_batch")] + \
+               [("mlp_ratio", C.c_float), ("bn_eps", C.c_float), ("bn_momentum", C.c_float)]
 
 
 class ProfEntry(C.Structure):
@@ -122,6 +131,19 @@ def _declare(lib):
     lib.porl_qnet_sync_target.argtypes = [vp, vp]
     lib.porl_qnet_forward.argtypes = [vp, C.c_int, vp, i64, i32, vp, i64, vp]
     lib.porl_qnet_penalty.argtypes = [vp, vp, i64, vp, i64, i32, vp, vp]
+    lib.porl_enc_create.argtypes = [C.POINTER(EncCfg), C.POINTER(vp)]
+    lib.porl_enc_destroy.argtypes = [vp]
+    lib.porl_enc_destroy.restype = None
+    for name in ("porl_enc_param_floats", "porl_enc_stat_floats", "porl_enc_workspace_floats"):
+        getattr(lib, name).argtypes = [vp]
+        getattr(lib, name).restype = i64
+    for name in ("porl_enc_tensors", "porl_enc_norms", "porl_enc_blocks"):
+        getattr(lib, name).argtypes = [vp]
+        getattr(lib, name).restype = i32
+    lib.porl_enc_tensor_info.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64), C.c_char_p, i32]
+    lib.porl_enc_norm_info.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.c_char_p, i32]
+    lib.porl_enc_bind.argtypes = [vp, vp, vp, vp]
+    lib.porl_enc_forward.argtypes = [vp, vp, i64, i32, i32, vp, vp, i64, vp]
     lib.porl_prof_enable.argtypes = [C.c_int]
     lib.porl_prof_read.argtypes = [C.POINTER(ProfEntry), C.c_int]
     for name in SYMBOLS:

@@ -1,0 +1,226 @@
+// Kernels of the costmap encoder forward (reference agent/fasternet.py:428-438, config 5): everything around
+// the 1x1-convolution GEMMs.  Activations are NHWC fp32 ("rows" = (sample, y, x) positions, channels
+// contiguous), so every 1x1 convolution is a plain (rows, Cin) x (Cout, Cin)^T product for gemm_f32.hpp
+// and all kernels here are HBM-bound row sweeps with 16-byte accesses.  64-bit row indices throughout:
+// batch 512 is 2.9 M positions of up to 384 channels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace porl {
+
+// ---------------------------------------------------------------------------------------------------
+// PatchEmbed.proj (fasternet.py:238, Conv2d(3, E, 4, stride 4, bias=False)) on the NCHW costmap image.
+// One block per (patch row, sample): the 3*4 image rows of the strip and the transposed weights sit in
+// LDS; lane = patch column, wave = channel quarter; k runs (c, ky, kx) ascending.
+//   img (B, 3, Hi, Wi), w (E, 48) -> out (B, Hi/4, Wi/4, E)
+// ---------------------------------------------------------------------------------------------------
+constexpr int PE_K = 48;
+__global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                          float* __restrict__ out, int Hi, int Wi, int E) {
+  extern __shared__ float pe_lds[];
+  float* strip = pe_lds;                 // [12][Wi]
+  float* wl = pe_lds + 12 * Wi;          // [48][E]
+  const int py = blockIdx.x, b = blockIdx.y, Hp = Hi >> 2, Wp = Wi >> 2;
+  for (int i = threadIdx.x; i < 12 * (Wi >> 2); i += 256) {
+    const int row = i / (Wi >> 2), x4 = i - row * (Wi >> 2);
+    const int c = row >> 2, ky = row & 3;
+    const float4 v = *reinterpret_cast<const float4*>(img + (((long)b * 3 + c) * Hi + 4 * py + ky) * Wi + 4 * x4);
+    *reinterpret_cast<float4*>(strip + row * Wi + 4 * x4) = v;
+  }
+  for (int i = threadIdx.x; i < PE_K * E; i += 256) {
+    const int e = i / PE_K, k = i - e * PE_K;
+    wl[k * E + e] = w[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, cq = threadIdx.x >> 6, eq = E >> 2;
+  for (int px = lane; px < Wp; px += 64) {
+    float* orow = out + (((long)b * Hp + py) * Wp + px) * E;
+    for (int c0 = cq * eq; c0 < (cq + 1) * eq; c0 += 8) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int row = 0; row < 12; ++row) {
+        const float4 a = *reinterpret_cast<const float4*>(strip + row * Wi + 4 * px);
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          const float* wk = wl + (row * 4 + kx) * E + c0;
+          const float4 w0 = *reinterpret_cast<const float4*>(wk), w1 = *reinterpret_cast<const float4*>(wk + 4);
+          acc[0] = fmaf(av[kx], w0.x, acc[0]); acc[1] = fmaf(av[kx], w0.y, acc[1]);
+          acc[2] = fmaf(av[kx], w0.z, acc[2]); acc[3] = fmaf(av[kx], w0.w, acc[3]);
+          acc[4] = fmaf(av[kx], w1.x, acc[4]); acc[5] = fmaf(av[kx], w1.y, acc[5]);
+          acc[6] = fmaf(av[kx], w1.z, acc[6]); acc[7] = fmaf(av[kx], w1.w, acc[7]);
+        }
+      }
+      *reinterpret_cast<float4*>(orow + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(orow + c0 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BatchNorm2d batch statistics (fasternet.py:164,240,255 in train mode): per-channel sum and sum of squares
+// of an (M, C) row-major activation, accumulated in fp64 like the CPU reference's accumulate type.
+// Stage 1: each block owns a contiguous row range and writes one partial per channel; stage 2 (one
+// thread per channel) adds the partials in block order, forms alpha = invstd*gamma, beta = bias - mean*alpha
+// and updates the running statistics (momentum, unbiased variance).
+// ---------------------------------------------------------------------------------------------------
+constexpr int CS_MAX_BLOCKS = 2048;
+__global__ __launch_bounds__(256) void colstats_partial_kernel(const float* __restrict__ x, long M, int C,
+                                                               double* __restrict__ partial) {
+  extern __shared__ double cs_lds[];      // [rows_par][2][C]
+  const int C4 = C >> 2, rows_par = 256 / C4;
+  const int c4 = threadIdx.x % C4, r = threadIdx.x / C4;
+  const long per = (M + gridDim.x - 1) / gridDim.x;
+  const long m0 = (long)blockIdx.x * per, m1 = m0 + per < M ? m0 + per : M;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (r < rows_par) {
+    for (long m = m0 + r; m < m1; m += rows_par) {
+      const float4 v = *reinterpret_cast<const float4*>(x + m * C + 4 * c4);
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      cs_lds[(r * 2 + 0) * C + 4 * c4 + j] = s[j];
+      cs_lds[(r * 2 + 1) * C + 4 * c4 + j] = q[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    double t = 0;
+    for (int rr = 0; rr < rows_par; ++rr) t += cs_lds[rr * 2 * C + i];
+    partial[(long)blockIdx.x * 2 * C + i] = t;
+  }
+}
+
+__global__ void bn_finish_kernel(const double* __restrict__ partial, int nblocks, int C, long M,
+                                 const float* __restrict__ gamma, const float* __restrict__ bias,
+                                 float* __restrict__ run_mean, float* __restrict__ run_var, int training,
+                                 double eps, double momentum, float* __restrict__ alpha, float* __restrict__ beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean_f, invstd_f;
+  if (training) {
+    double s = 0, q = 0;
+    for (int b = 0; b < nblocks; ++b) {
+      s += partial[(long)b * 2 * C + c];
+      q += partial[(long)b * 2 * C + C + c];
+    }
+    const double mean = s / (double)M;
+    double var = q / (double)M - mean * mean;
+    if (var < 0) var = 0;
+    mean_f = (float)mean;
+    invstd_f = (float)(1.0 / sqrt(var + eps));
+    const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+    run_mean[c] = (float)(momentum * mean + (1.0 - momentum) * (double)run_mean[c]);
+    run_var[c] = (float)(momentum * unbiased + (1.0 - momentum) * (double)run_var[c]);
+  } else {
+    mean_f = run_mean[c];
+    invstd_f = (float)(1.0 / sqrt((double)run_var[c] + eps));
+  }
+  const float a = __fmul_rn(invstd_f, gamma[c]);
+  alpha[c] = a;
+  beta[c] = __fsub_rn(bias[c], __fmul_rn(mean_f, a));
+}
+
+// y = x*alpha[c] + beta[c] (+ReLU), in place or not; n4 = M*C/4 float4 items
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, int C4,
+                                                       const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                       int relu) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 a = reinterpret_cast<const float4*>(alpha)[c4], b = reinterpret_cast<const float4*>(beta)[c4];
+    float4 o = make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Partial_conv3 (fasternet.py:110-138): 3x3, pad 1, on the first Cp channels.  This kernel lays the
+// (rows, 9*Cp) patch matrix out for the GEMM, k = (ky, kx, ci), zero outside the image, and copies the
+// untouched channels Cp..C-1 of x into y (the `cat` of forward_split_cat, :132-136).
+//   x (B, H, W, C) -> col (B*H*W, 9*Cp), y[:, Cp:] = x[:, Cp:]
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, float* __restrict__ col,
+                                                        float* __restrict__ y, long rows, int H, int W, int C, int Cp) {
+  const int cp4 = Cp >> 2, rest4 = (C - Cp) >> 2, per_row = 9 * cp4 + rest4;
+  const long total = rows * per_row;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / per_row;
+    const int j = (int)(i - m * per_row);
+    if (j < 9 * cp4) {
+      const int t = j / cp4, ci4 = j - t * cp4;
+      const int ky = t / 3, kx = t - ky * 3;
+      const int xx = (int)(m % W), yy = (int)((m / W) % H);
+      const int sy = yy + ky - 1, sx = xx + kx - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sy >= 0 && sy < H && sx >= 0 && sx < W)
+        v = *reinterpret_cast<const float4*>(x + (m + (long)(ky - 1) * W + (kx - 1)) * C + 4 * ci4);
+      *reinterpret_cast<float4*>(col + m * (9L * Cp) + (long)t * Cp + 4 * ci4) = v;
+    } else {
+      const int c = Cp + 4 * (j - 9 * cp4);
+      *reinterpret_cast<float4*>(y + m * C + c) = *reinterpret_cast<const float4*>(x + m * C + c);
+    }
+  }
+}
+
+// x[m, :] += scale[sample(m)] * z[m, :]   (MLPBlock.forward, fasternet.py:186-190; scale is the DropPath
+// keep mask already divided by keep_prob, :86-93; NULL = 1).  Product and sum rounded separately, as
+// eager PyTorch does.
+__global__ __launch_bounds__(256) void residual_kernel(float* __restrict__ x, const float* __restrict__ z, long n4,
+                                                       long per_sample4, const float* __restrict__ scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float s = scale ? scale[i / per_sample4] : 1.f;
+    const float4 a = reinterpret_cast<const float4*>(x)[i], b = reinterpret_cast<const float4*>(z)[i];
+    reinterpret_cast<float4*>(x)[i] = make_float4(__fadd_rn(a.x, __fmul_rn(b.x, s)), __fadd_rn(a.y, __fmul_rn(b.y, s)),
+                                                  __fadd_rn(a.z, __fmul_rn(b.z, s)), __fadd_rn(a.w, __fmul_rn(b.w, s)));
+  }
+}
+
+// PatchMerging.reduction input (fasternet.py:253, Conv2d(C, 2C, 2, stride 2)): (B, H, W, C) -> (B*H/2*W/2, 4C)
+// with k = (ky, kx, c)
+__global__ __launch_bounds__(256) void space_to_depth_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                             long out_rows, int H, int W, int C) {
+  const int c4n = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const long total = out_rows * 4 * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / (4 * c4n);
+    const int j = (int)(i - m * 4 * c4n);
+    const int t = j / c4n, c4 = j - t * c4n, ky = t >> 1, kx = t & 1;
+    const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho);
+    const long b = m / ((long)Wo * Ho);
+    const long src = ((b * H + 2 * oy + ky) * W + 2 * ox + kx) * C + 4 * c4;
+    reinterpret_cast<float4*>(out)[i] = *reinterpret_cast<const float4*>(x + src);
+  }
+}
+
+// AdaptiveAvgPool2d(1) (fasternet.py:368): mean over the P positions of each sample; 64 channels x 4 row
+// lanes per block, fp64 partial sums combined in lane order.   x (B, P, C) -> out (B, C)
+__global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, float* __restrict__ out, int P, int C) {
+  __shared__ double part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+  const long b = blockIdx.y;
+  double s = 0;
+  if (c < C)
+    for (int p = r; p < P; p += 4) s += x[(b * P + p) * C + c];
+  part[r][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (r == 0 && c < C) {
+    const double t = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    out[b * C + c] = (float)(t / (double)P);
+  }
+}
+
+// conv weight (O, I, KH, KW) -> (O, KH, KW, I): the k order the patch matrices above use
+__global__ void permute_oihw_ohwi_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int I, int KK) {
+  const int n = O * I * KK;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int o = i / (I * KK), rem = i - o * I * KK, t = rem / I, ci = rem - t * I;
+    dst[i] = src[((long)o * I + ci) * KK + t];
+  }
+}
+
+}  // namespace porl

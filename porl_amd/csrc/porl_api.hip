@@ -1282,3 +1282,5 @@ int porl_qnet_penalty(porl_qnet* h, const float* states, int64_t s_rs, const int
 }
 
 }  // extern "C"
+
+#include "encoder_api.inc"

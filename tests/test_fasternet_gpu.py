@@ -1,0 +1,139 @@
+"""Costmap encoder (FasterNet.forward_cls, reference agent/fasternet.py:428-438) on the device against the
+reference's golden vectors (tests/golden/fasternet_b5.npz, generated from /root/reference by
+oracle/gen_golden.py), against the numpy oracle on fresh inputs, and — at the batch of BASELINE config 5 —
+through size-independent properties.  Tolerance: 2e-5 of the largest feature magnitude (fp32, different
+summation orders through 11 convolutions and 5 BatchNorms)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, checksum, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+REL = 2e-5
+
+
+def rel_err(got, ref):
+    return float(np.abs(np.asarray(got, dtype=np.float64) - ref).max() / np.abs(ref).max())
+
+
+def build(seed, max_batch=8):
+    from porl_amd.agent.fasternet import FasterNet
+    torch.manual_seed(seed)
+    return FasterNet(3, 256, max_batch=max_batch).to(DEV)
+
+
+def test_weights_are_the_reference_initialisation():
+    z, _ = load_golden("fasternet_b5")
+    m = build(int(z["seed_model"]))
+    for i, (k, v) in enumerate(m.state_dict().items()):
+        if v.dim():
+            cs, ref = checksum(v.cpu().numpy(), i), z["wsum." + k]
+            # trunc_normal_'s erfinv_ is vectorised differently across host CPUs: ulp-level differences
+            assert np.allclose(cs, ref, rtol=1e-6, atol=1e-9), k
+
+
+def test_eval_and_train_forward_match_reference_golden():
+    z, _ = load_golden("fasternet_b5")
+    m = build(int(z["seed_model"]))
+    m.eval()
+    f = m(torch.from_numpy(z["states"].copy()).to(DEV))
+    assert rel_err(f.cpu().numpy(), z["feat_eval"]) < REL
+    m.train()
+    f1 = m(torch.from_numpy(z["states"].copy()).to(DEV), drop_scale=torch.from_numpy(z["drop_scale1"]))
+    f2 = m(torch.from_numpy(z["states2"].copy()).to(DEV), drop_scale=torch.from_numpy(z["drop_scale2"]))
+    assert rel_err(f1.cpu().numpy(), z["feat_train1"]) < REL
+    assert rel_err(f2.cpu().numpy(), z["feat_train2"]) < REL
+    sd = m.state_dict()
+    for k in sd:
+        if k.endswith("running_var"):
+            ref = z["stat_after." + k]
+            assert rel_err(sd[k].cpu().numpy(), ref) < 1e-5, k
+            mean_ref = z["stat_after." + k.replace("running_var", "running_mean")]
+            got = sd[k.replace("running_var", "running_mean")].cpu().numpy()
+            # channel means sit near zero: compare on the scale of the channel's standard deviation
+            assert np.abs(got - mean_ref).max() < 1e-5 * np.sqrt(ref.max() / 0.19), k
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(z["stat_after." + k]) == 2
+    m.eval()
+    f3 = m(torch.from_numpy(z["states"].copy()).to(DEV))
+    assert rel_err(f3.cpu().numpy(), z["feat_eval_after"]) < REL
+
+
+def test_droppath_masks_come_from_the_cpu_generator_in_reference_order():
+    z, _ = load_golden("fasternet_b5")
+    m = build(int(z["seed_model"]))
+    m.train()
+    torch.manual_seed(int(z["seed_fwd"]))
+    f1 = m(torch.from_numpy(z["states"].copy()).to(DEV))
+    f2 = m(torch.from_numpy(z["states2"].copy()).to(DEV))
+    assert rel_err(f1.cpu().numpy(), z["feat_train1"]) < REL
+    assert rel_err(f2.cpu().numpy(), z["feat_train2"]) < REL
+
+
+def test_against_oracle_on_fresh_inputs_and_state_is_clamped_in_place():
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import fasternet_oracle as FO
+    m = build(5)
+    sd = {k: v.cpu().numpy().copy() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(3)
+    st = np.empty((3, 362), dtype=np.float32)
+    st[:, :360] = rng.uniform(0.2, 3.9, size=(3, 360))
+    st[:, 360:] = rng.uniform(-3, 3, size=(3, 2))
+    st[1, 7] = 9.0
+    scale = np.array([[1, 1, 1], [0, 1 / 0.95, 1 / 0.95], [1 / 0.9, 0, 1 / 0.9]], dtype=np.float32)
+    stats = {k: v.copy() for k, v in sd.items() if "running" in k}
+    x_ref = st.copy()
+    ref = FO.forward(sd, stats, x_ref, True, scale)
+    m.train()
+    x = torch.from_numpy(st.copy()).to(DEV)
+    got = m(x, drop_scale=torch.from_numpy(scale))
+    assert rel_err(got.cpu().numpy(), ref) < REL
+    assert np.array_equal(x.cpu().numpy(), x_ref) and x_ref[1, 7] == 0.0       # costmap.py:17 side effect
+
+
+def test_full_batch_properties():
+    """B=512 (BASELINE config 5; 2.9 M stage-1 positions, GEMM operands split at the 2 GiB descriptor reach):
+    eval-mode features of a sample do not depend on its batch neighbours, bit for bit; train mode is
+    deterministic; a dropped sample of a block equals the block-skipped network."""
+    B = 512
+    m = build(1, max_batch=B)
+    rng = np.random.default_rng(9)
+    st = np.empty((B, 362), dtype=np.float32)
+    st[:, :360] = rng.uniform(0.2, 3.9, size=(B, 360))
+    st[:, 360:] = rng.uniform(-3, 3, size=(B, 2))
+    m.eval()
+    big = m(torch.from_numpy(st.copy()).to(DEV))
+    assert torch.isfinite(big).all()
+    pick = [0, 1, 255, 256, 484, 485, 486, 511]
+    small = m(torch.from_numpy(st[pick].copy()).to(DEV))
+    assert torch.equal(big[pick], small)
+    m.train()
+    scale = torch.ones(3, B)
+    scale[1, ::3] = 0
+    scale[2, 1::3] = 0
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    a = m(torch.from_numpy(st.copy()).to(DEV), drop_scale=scale)
+    m.load_state_dict(before)
+    b = m(torch.from_numpy(st.copy()).to(DEV), drop_scale=scale)
+    assert torch.equal(a, b)
+    assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+
+
+def test_errors():
+    from porl_amd import _native as N
+    from porl_amd.agent.fasternet import FasterNet
+    m = FasterNet(3, 256, max_batch=2)
+    with pytest.raises(N.NativeError):
+        m(torch.zeros(1, 362))                                   # no CPU path
+    m = m.to(DEV)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 100, device=DEV))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(3, 362, device=DEV))                       # > max_batch
+    with pytest.raises(NotImplementedError):
+        FasterNet(3, 256, fork_feat=True)
