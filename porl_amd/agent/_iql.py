@@ -146,6 +146,9 @@ class IqlAgentBase(nn.Module):
         self._engine.to(probe.device)
         self.device = probe.device
         self._adopt()
+        backbone = getattr(self, "backbone", None)
+        if backbone is not None:
+            backbone._apply(fn)
         return self
 
     # ---------------------------------------------------------------------------------------------

@@ -1,4 +1,5 @@
-"""SORL agent — drop-in for /root/reference/agent/sorl.py:20-152 (backbone=None) on one MI355X.
+"""SORL agent — drop-in for /root/reference/agent/sorl.py:20-152 on one MI355X, with or without the costmap
+encoder as `backbone` (sorl_train.py:29-33: `FasterNet(3, args.feature_dim)`, porl_amd/agent/fasternet.py).
 
 Same constructor and attribute names (`v_net`, `policy`, `v_tgt`, `v_optimizer`, `policy_optimizer`,
 `lr_schedule`), `update`, `vf_update`, `select_action`.  Value step == POR's; the policy step is
@@ -24,18 +25,20 @@ class SORL(IqlAgentBase):
     def __init__(agent, args, max_steps, tau, alpha, device=torch.device('cpu'), backbone=None,
                  value_lr=1e-4, policy_lr=1e-4, discount=0.99, beta=0.005):
         super().__init__()
-        if backbone is not None:
-            raise NotImplementedError("SORL(backbone=...) (FasterNet encoder) is outside the accelerated path")
         agent.device = torch.device(device)
-        agent.backbone = None
+        agent.backbone = backbone
+        # with a backbone the heads see its features (sorl.py:46-56); it joins no optimizer (sorl.py:58-64)
+        in_dim = args.state_size if backbone is None else args.feature_dim
+        if backbone is not None:
+            agent.backbone = backbone.to(agent.device)
         # SORL builds the value net BEFORE the policy (sorl.py:37-45)
-        agent.v_net = TwinV(args.state_size, layer_norm=args.layer_norm,
+        agent.v_net = TwinV(in_dim, layer_norm=args.layer_norm,
                             hidden_dim=args.hidden_dim, n_hidden=args.n_hidden)
-        agent.policy = BoundedGaussianPolicy(args.state_size, args.action_size,
+        agent.policy = BoundedGaussianPolicy(in_dim, args.action_size,
                                              hidden_dim=args.hidden_dim, n_hidden=args.n_hidden)
         agent.v_tgt = copy.deepcopy(agent.v_net).requires_grad_(False)
         agent._setup_engine(agent.v_net, agent.v_tgt, agent.policy,
-                            obs_dim=args.state_size, pol_out_dim=args.action_size, hidden_dim=args.hidden_dim,
+                            obs_dim=in_dim, pol_out_dim=args.action_size, hidden_dim=args.hidden_dim,
                             n_hidden=args.n_hidden, layer_norm=args.layer_norm, pol_tanh=True, weight_mode=1,
                             device=agent.device, max_batch=int(getattr(args, "max_batch", 0) or
                                                                getattr(args, "batch_size", 0) or 1024))
@@ -50,15 +53,25 @@ class SORL(IqlAgentBase):
     def select_action(agent, observations):
         """Mean action as a numpy array (reference sorl.py:71-76)."""
         agent.flush()
+        if agent.backbone is not None:
+            observations = agent.backbone(observations)
         return agent.policy(observations).mean.cpu().numpy()
 
     def update(agent, observations, actions, rewards, next_observations, terminals):
-        """Joint value + policy step (reference sorl.py:78-128) -> (v_loss, g_loss)."""
+        """Joint value + policy step (reference sorl.py:78-128) -> (v_loss, g_loss).  With a backbone both
+        observation batches are encoded first, s then s' (sorl.py:81-83); the encoder is forward-only because
+        nothing ever consumes its gradients."""
+        if agent.backbone is not None:
+            observations = agent.backbone(observations)
+            next_observations = agent.backbone(next_observations)
         return agent._full_update(observations, next_observations, rewards, terminals, actions,
                                   agent.v_optimizer, agent.policy_optimizer, agent.lr_schedule)
 
     def vf_update(agent, observations, actions, rewards, next_observations, terminals):
         """Value step only (reference sorl.py:130-152) -> v_loss."""
+        if agent.backbone is not None:
+            observations = agent.backbone(observations)
+            next_observations = agent.backbone(next_observations)
         agent._value_update(observations, next_observations, rewards, terminals, agent.v_optimizer)
         if agent.async_losses:
             return agent._engine.stats[:1]

@@ -137,3 +137,45 @@ def test_errors():
         m(torch.zeros(3, 362, device=DEV))                       # > max_batch
     with pytest.raises(NotImplementedError):
         FasterNet(3, 256, fork_feat=True)
+
+
+def test_sorl_update_with_encoder_backbone_matches_reference_golden():
+    """SORL.update with backbone=FasterNet(3, 256) (sorl.py:78-128, sorl_train.py:29-33): three joint updates,
+    DropPath masks drawn by the drop-in itself from the seeded CPU generator in the reference's order.
+    Features carry ~1e-6 relative noise (different conv summation orders), which the 64-wide heads pass on."""
+    from types import SimpleNamespace
+    from porl_amd.agent.fasternet import FasterNet
+    from porl_amd.agent.sorl import SORL
+    z, _ = load_golden("sorl_enc_b6")
+    B, K, H, L, A, F = (int(v) for v in z["meta"])
+    torch.manual_seed(int(z["seed_model"]))
+    backbone = FasterNet(3, F, max_batch=B)
+    args = SimpleNamespace(state_size=362, feature_dim=F, hidden_dim=H, n_hidden=L, layer_norm=False, action_size=A,
+                           max_batch=B)
+    agent = SORL(args, max_steps=50, tau=float(z["tau"]), alpha=float(z["alpha"]), device=DEV, backbone=backbone)
+    sd = agent.state_dict()
+    for k in z.files:
+        if k.startswith("init."):
+            assert np.array_equal(sd[k[5:]].cpu().numpy(), z[k]), k         # heads: same generator stream
+    torch.manual_seed(int(z["seed_fwd"]))
+    for k in range(K):
+        t = lambda n: torch.from_numpy(z[f"{n}{k}"].copy()).to(DEV)
+        vl, gl = agent.update(t("s"), t("a"), t("r"), t("s2"), t("d"))
+        np.testing.assert_allclose([vl, gl], z["losses"][k], rtol=5e-5)
+    sd = agent.state_dict()
+    worst = 0.0
+    for k in z.files:
+        if not k.startswith("final."):
+            continue
+        got, ref = sd[k[6:]].cpu().numpy().astype(np.float64), z[k]
+        if "num_batches" in k:
+            assert int(got) == int(ref) == 2 * K
+        elif "running_mean" in k:
+            assert np.abs(got - ref).max() < 1e-5, k
+        elif "running_var" in k:
+            assert rel_err(got, ref) < 1e-5, k
+        else:
+            worst = max(worst, float(np.abs(got - ref).max()))
+    assert worst < 2e-5, worst                                               # lr 1e-4, 3 Adam steps
+    act = agent.select_action(torch.from_numpy(z["s0"].copy()).to(DEV))
+    assert act.shape == (B, A) and np.isfinite(act).all()

@@ -1,9 +1,12 @@
 """Pins oracle/por_oracle.py against golden vectors recorded from the reference itself
 (oracle/gen_golden.py).  CPU only."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
-from conftest import load_golden, sub, checksum
+from conftest import REPO, load_golden, sub, checksum
 from oracle.por_oracle import PorOracle, sorl_oracle, CqlOracle
 from porl_amd.util.synth import make_rows, split_rows, make_discrete_transitions
 
@@ -126,3 +129,51 @@ def test_cql_learn(name):
     idx = z["indices"][0]
     np.testing.assert_allclose(o.penalty(st[idx], ac[idx]), float(z["penalty_final_on_batch0"]),
                                atol=2e-6)
+
+
+# ---- costmap encoder (oracle/fasternet_oracle.py) ------------------------------------------------------
+def test_costmap_oracle_matches_reference_golden():
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import fasternet_oracle as FO
+    z, _ = load_golden("costmap_b24")
+    st = z["state_in"].copy()
+    out = FO.state2costmap(st)
+    nz = np.argwhere(out != 0).astype(np.int32)
+    assert np.array_equal(nz, z["nonzero"])
+    assert np.array_equal(st, z["state_after"])
+
+
+def test_fasternet_oracle_matches_reference_golden():
+    """Weights come from the drop-in's constructor (same seed => the reference's initialisation, pinned by the
+    fixture's per-tensor checksums); the oracle then reproduces the reference's eval and train forwards,
+    its intermediate activations and its BatchNorm running statistics."""
+    import torch
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import fasternet_oracle as FO
+    from porl_amd.agent.fasternet import FasterNet
+    z, _ = load_golden("fasternet_b5")
+    torch.manual_seed(int(z["seed_model"]))
+    m = FasterNet(3, 256)
+    sd = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    for i, (k, v) in enumerate(sd.items()):
+        if v.ndim:
+            assert np.allclose(checksum(v, i), z["wsum." + k], rtol=1e-6, atol=1e-9), k
+    stats = {k: v.copy() for k, v in sd.items() if "running" in k}
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    taps = {}
+    f = FO.forward(sd, stats, z["states"].copy(), False, taps=taps)
+    assert rel(f, z["feat_eval"]) < 5e-6
+    for k, v in taps.items():
+        v = v.reshape(v.shape[0], v.shape[1], -1) if v.ndim == 4 else v
+        mine = np.concatenate([[v.sum(), np.abs(v).sum()], v[:, :6].reshape(v.shape[0], -1)[:, :24].ravel()])
+        assert rel(mine, z["tap_eval." + k]) < 5e-6, k
+    f1 = FO.forward(sd, stats, z["states"].copy(), True, z["drop_scale1"])
+    f2 = FO.forward(sd, stats, z["states2"].copy(), True, z["drop_scale2"])
+    assert rel(f1, z["feat_train1"]) < 5e-6 and rel(f2, z["feat_train2"]) < 5e-6
+    for k in stats:
+        if k.endswith("running_var"):
+            assert rel(stats[k], z["stat_after." + k]) < 2e-6, k
+        elif k.endswith("running_mean"):
+            assert np.abs(stats[k] - z["stat_after." + k]).max() < 1e-6, k
+    f3 = FO.forward(sd, stats, z["states"].copy(), False)
+    assert rel(f3, z["feat_eval_after"]) < 2e-5     # the reference's own fp32 noise: features ~1e-3 here
