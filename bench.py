@@ -133,18 +133,102 @@ def bench_cql(a):
                                        "sample": f"{n} oracle learn() calls incl. numpy sampling in 5 s"}}), flush=True)
 
 
+def bench_sorl_enc(a):
+    """Secondary workload (BASELINE config 5): SORL.update with the FasterNet costmap encoder as backbone, B=512,
+    S=362 (360 beams + goal), feature_dim=256, H=512, fp32 (the parity bar is 1e-5, so no bf16).  One step =
+    encode s, encode s' (train-mode BatchNorm, DropPath), value + policy update.  Reports the per-kernel time
+    split of one step from an instrumented second pass."""
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    from porl_amd.agent.fasternet import FasterNet
+    from porl_amd.agent.sorl import SORL
+    from porl_amd import engine as E
+    dev = torch.device("cuda", 0)
+    Bq, F, Hq, Aq = a.batch or 512, 256, 512, 2
+    torch.manual_seed(0)
+    backbone = FasterNet(3, F, max_batch=Bq)
+    args = SimpleNamespace(state_size=362, feature_dim=F, hidden_dim=Hq, n_hidden=2, layer_norm=False, action_size=Aq,
+                           max_batch=Bq)
+    agent = SORL(args, max_steps=1000, tau=0.9, alpha=3.0, device=dev, backbone=backbone)
+    agent.async_losses = True
+    rng = np.random.default_rng(0)
+    nb = 4
+    st = np.empty((nb, 2, Bq, 362), dtype=np.float32)
+    st[..., :360] = rng.uniform(0.15, 3.9, size=(nb, 2, Bq, 360))
+    st[..., 360:] = rng.uniform(-3, 3, size=(nb, 2, Bq, 2))
+    st = torch.from_numpy(st).to(dev)
+    act = torch.from_numpy(rng.uniform(-1, 1, size=(nb, Bq, Aq)).astype(np.float32)).to(dev)
+    rew = torch.from_numpy(rng.normal(size=(nb, Bq)).astype(np.float32)).to(dev)
+    done = torch.from_numpy((rng.uniform(size=(nb, Bq)) < 0.1).astype(np.float32)).to(dev)
+
+    def one_step(i):
+        k = i % nb
+        agent.update(st[k, 0], act[k], rew[k], st[k, 1], done[k])
+
+    for i in range(a.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        one_step(i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    losses = agent._engine.stats[:2].cpu().numpy()
+    if not np.isfinite(losses).all():
+        raise SystemExit("non-finite loss in the benchmark run")
+    E.prof_enable(True)
+    for i in range(a.steps):
+        one_step(i)
+    prof = E.prof_read()
+    E.prof_enable(False)
+    split = {p["name"]: p["total_ms"] / a.steps for p in prof if p["launches"]}
+    gemms = [p for p in prof if p["name"].startswith("gemm_f32_kernel") and p["launches"]]
+    dom = max(gemms, key=lambda p: p["total_ms"])
+    ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+    enc_flops = 2 * 2 * Bq * 0.86e9
+    out = {"metric": "gradient-steps/sec (SORL update + FasterNet encoder, batch=512)", "value": a.steps / el,
+           "unit": "gradient-steps/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"SORL S=362 F={F} H={Hq} B={Bq} + FasterNet(3,{F}) encoder on 360x256 costmaps, "
+                                  "2 encoder forwards (train-mode BN, DropPath) + value/policy update per step"},
+           "algorithmic_tflops": enc_flops * a.steps / el / 1e12,
+           "roofline": dict(bound="mfma", kernel=dom["name"], achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=None, launches=dom["launches"],
+                            avg_launch_us=1e3 * dom["total_ms"] / dom["launches"], all_kernels_ms_per_step=split)}
+    if not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(REPO, "oracle"))
+        import fasternet_oracle as FO
+        sd = {k: v.cpu().numpy() for k, v in backbone.state_dict().items()}
+        stats = {k: v.copy() for k, v in sd.items() if "running" in k}
+        bs = 8
+        x = st[0, 0, :bs].cpu().numpy()
+        c0 = time.perf_counter()
+        FO.forward(sd, stats, x.copy(), True, np.ones((3, bs), np.float32), dtype=np.float32)
+        FO.forward(sd, stats, x.copy(), True, np.ones((3, bs), np.float32), dtype=np.float32)
+        dt = time.perf_counter() - c0
+        out["cpu_baseline"] = {"value": (bs / Bq) / dt, "unit": "gradient-steps/sec", "kind": "port", "cores": os.cpu_count(),
+                               "sample": f"2 encoder forwards of oracle/fasternet_oracle.py (numpy fp32) on {bs} of the "
+                                         f"{Bq} samples in {dt:.1f} s, scaled by {bs}/{Bq}; heads' update excluded (<1 %)"}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="por", choices=["por", "cql"])
+    ap.add_argument("--workload", default="por", choices=["por", "cql", "sorl_enc"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows-per-gpu", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
     if a.workload == "cql":
         return bench_cql(a)
+    if a.workload == "sorl_enc":
+        return bench_sorl_enc(a)
 
     import numpy as np
     import torch

@@ -94,34 +94,44 @@ __global__ __launch_bounds__(256) void colstats_partial_kernel(const float* __re
   }
 }
 
-__global__ void bn_finish_kernel(const double* __restrict__ partial, int nblocks, int C, long M,
-                                 const float* __restrict__ gamma, const float* __restrict__ bias,
-                                 float* __restrict__ run_mean, float* __restrict__ run_var, int training,
-                                 double eps, double momentum, float* __restrict__ alpha, float* __restrict__ beta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one wave per channel: lanes add the block partials in a fixed strided order, then a shuffle tree
+__global__ __launch_bounds__(64) void bn_finish_kernel(const double* __restrict__ partial, int nblocks, int C, long M,
+                                                       const float* __restrict__ gamma, const float* __restrict__ bias,
+                                                       float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                       int training, double eps, double momentum,
+                                                       float* __restrict__ alpha, float* __restrict__ beta) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   float mean_f, invstd_f;
   if (training) {
     double s = 0, q = 0;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = lane; b < nblocks; b += 64) {
       s += partial[(long)b * 2 * C + c];
       q += partial[(long)b * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o);
+      q += __shfl_xor(q, o);
     }
     const double mean = s / (double)M;
     double var = q / (double)M - mean * mean;
     if (var < 0) var = 0;
     mean_f = (float)mean;
     invstd_f = (float)(1.0 / sqrt(var + eps));
-    const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-    run_mean[c] = (float)(momentum * mean + (1.0 - momentum) * (double)run_mean[c]);
-    run_var[c] = (float)(momentum * unbiased + (1.0 - momentum) * (double)run_var[c]);
+    if (lane == 0) {
+      const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+      run_mean[c] = (float)(momentum * mean + (1.0 - momentum) * (double)run_mean[c]);
+      run_var[c] = (float)(momentum * unbiased + (1.0 - momentum) * (double)run_var[c]);
+    }
   } else {
     mean_f = run_mean[c];
     invstd_f = (float)(1.0 / sqrt((double)run_var[c] + eps));
   }
-  const float a = __fmul_rn(invstd_f, gamma[c]);
-  alpha[c] = a;
-  beta[c] = __fsub_rn(bias[c], __fmul_rn(mean_f, a));
+  if (lane == 0) {
+    const float a = __fmul_rn(invstd_f, gamma[c]);
+    alpha[c] = a;
+    beta[c] = __fsub_rn(bias[c], __fmul_rn(mean_f, a));
+  }
 }
 
 // y = x*alpha[c] + beta[c] (+ReLU), in place or not; n4 = M*C/4 float4 items
@@ -164,6 +174,96 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict_
       const int c = Cp + 4 * (j - 9 * cp4);
       *reinterpret_cast<float4*>(y + m * C + c) = *reinterpret_cast<const float4*>(x + m * C + c);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Partial_conv3 as a direct convolution (the patch matrix above costs more HBM traffic than the conv costs
+// FLOPs).  One block = 64 lanes x (OCB/8) waves on a tile of TR rows x W columns of one sample:
+// lane = (row, group of 4 consecutive x), wave = group of 8 output channels.  The input tile with its halo
+// sits in LDS channel-planar ([row][ci][x], x shifted by 4 so the 4 centre values are one aligned 16-byte
+// read).  The weights of a wave are uniform, so they arrive through the scalar cache (s_load_dwordx8 from the
+// [ky][ci][kx][oc] copy made by pack_pconv_kernel) and feed v_pk_fma_f32 as SGPR pairs: no LDS traffic and no
+// VGPRs for them, 48 packed FMAs per 3 LDS reads.  blockIdx.z selects the OCB-wide slice of output channels.
+// Also copies the untouched channels Cp..C-1 (slice 0 only).
+//   x (B, H, W, C) -> y[:, :Cp] = conv3x3(x[:, :Cp]), y[:, Cp:] = x[:, Cp:]
+// ---------------------------------------------------------------------------------------------------
+template <int CP, int OCB, int W>
+__global__ __launch_bounds__(64 * (OCB / 8)) void pconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                  float* __restrict__ y, int H, int C) {
+  constexpr int XG = W / 4, TR = 64 / XG, RS = W + 8, NT = 64 * (OCB / 8);
+  static_assert(W % 4 == 0 && 64 % XG == 0 && OCB % 8 == 0 && CP % OCB == 0 && CP % 4 == 0, "tile shape");
+  extern __shared__ float pc_lds[];
+  float* hl = pc_lds;                              // [TR + 2][CP][RS]
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r0 = blockIdx.x * TR, oc0 = blockIdx.z * OCB;
+  const long b = blockIdx.y;
+  const float* xs = x + b * H * W * C;
+  float* ys = y + b * H * W * C;
+  // input rows r0-1 .. r0+TR, columns -1 .. W, CP channels; zeros outside the image
+  constexpr int CP4 = CP / 4;
+  for (int i = t; i < (TR + 2) * (W + 2) * CP4; i += NT) {
+    const int c4 = i % CP4, xx = (i / CP4) % (W + 2), rr = i / (CP4 * (W + 2));
+    const int gy = r0 + rr - 1, gx = xx - 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const float4*>(xs + ((long)gy * W + gx) * C + 4 * c4);
+    float* d = hl + (rr * CP + 4 * c4) * RS + gx + 4;
+    d[0] = v.x; d[RS] = v.y; d[2 * RS] = v.z; d[3 * RS] = v.w;
+  }
+  __syncthreads();
+  const int row = lane / XG, xg = lane % XG;
+  float acc[4][8];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[p][o] = 0.f;
+  const float* wbase = wp + oc0 + wave * 8;
+#pragma unroll 1
+  for (int ky = 0; ky < 3; ++ky) {
+    const float* hrow = hl + (row + ky) * CP * RS + 4 * xg + 4;
+#pragma unroll 2
+    for (int ci = 0; ci < CP; ++ci) {
+      const float4 mid = *reinterpret_cast<const float4*>(hrow + ci * RS);
+      const float in[6] = {hrow[ci * RS - 1], mid.x, mid.y, mid.z, mid.w, hrow[ci * RS + 4]};
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float* wk = wbase + ((ky * CP + ci) * 3 + kx) * CP;
+        float wv[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) wv[o] = wk[o];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int o = 0; o < 8; ++o) acc[p][o] = fmaf(in[p + kx], wv[o], acc[p][o]);
+      }
+    }
+  }
+  const int gy = r0 + row;
+  if (gy < H) {
+    float* o = ys + ((long)gy * W + 4 * xg) * C + oc0 + wave * 8;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<float4*>(o + (long)p * C) = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+      *reinterpret_cast<float4*>(o + (long)p * C + 4) = make_float4(acc[p][4], acc[p][5], acc[p][6], acc[p][7]);
+    }
+  }
+  if (blockIdx.z == 0) {
+    const int rest4 = (C - CP) / 4, rows_here = min(TR, H - r0);
+    const long base = (long)r0 * W * C;
+    for (int i = t; i < rows_here * W * rest4; i += NT) {
+      const int c4 = i % rest4, pos = i / rest4;
+      const long off = base + (long)pos * C + CP + 4 * c4;
+      *reinterpret_cast<float4*>(ys + off) = *reinterpret_cast<const float4*>(xs + off);
+    }
+  }
+}
+
+// conv weight (Cp, Cp, 3, 3) -> [ky][ci][kx][oc], the order pconv3x3_kernel walks
+__global__ void pack_pconv_kernel(const float* __restrict__ src, float* __restrict__ dst, int CP) {
+  const int n = CP * CP * 9;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int oc = i % CP, kx = (i / CP) % 3, ci = (i / (3 * CP)) % CP, ky = i / (3 * CP * CP);
+    dst[i] = src[((long)oc * CP + ci) * 9 + ky * 3 + kx];
   }
 }
 
