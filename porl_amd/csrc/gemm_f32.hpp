@@ -54,6 +54,10 @@ struct GemmProb {
   float* rawdot;          // !A_KC + APRO only: (M,) sum_k rowscale[k] * A_raw(k, m)  (scalar-head weight gradient)
   const float* a_rowscale;  // APRO_RANK1_MASK
   const float* a_colscale;  // APRO_RANK1_MASK
+  const float* resid;     // (M,N) ld=ldc: C = resid + rscale[(row + rs_row0) / rs_rows] * acc (may alias C), or null
+  const float* rscale;    // per-sample factor of the residual form (null = 1)
+  float* cstat;           // ((M+31)/32, 2, N): per 32-row block, column sums and sums of squares of the stored C
+  int rs_rows, rs_row0;
   int M, N, K;
   int lda, ldb, ldc, ldmask;
   int act;
@@ -672,6 +676,34 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
           vals[r] = (ok && mv > 0.f) ? vals[r] : 0.f;
         }
       }
+      if (!raw && P.resid && !fast_c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (row < M && col_ok) {
+            const float rs = P.rscale ? P.rscale[(row + P.rs_row0) / P.rs_rows] : 1.f;
+            vals[r] = __fadd_rn(P.resid[(size_t)row * P.ldc + col], __fmul_rn(vals[r], rs));
+          }
+        }
+      }
+      if (!raw && P.cstat) {
+        // this lane holds 16 rows of one column of a 32-row block; the other 16 rows sit 32 lanes away
+        float cs = 0.f, cq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          const float v = row < M ? vals[r] : 0.f;
+          cs += v;
+          cq = fmaf(v, v, cq);
+        }
+        cs += __shfl_xor(cs, 32);
+        cq += __shfl_xor(cq, 32);
+        if (kh == 0 && col_ok) {
+          float* o = P.cstat + (size_t)((m0 + wm * (BM / WM)) / 32 + i) * 2 * N + col;
+          o[0] = cs;
+          o[N] = cq;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) hsum[r] += vals[r] * hw;
       if (store_c) {
@@ -722,6 +754,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
         const float4 mk = *reinterpret_cast<const float4*>(maskp + (size_t)(wr0 + r) * P.ldmask + wc0 + c);
         v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
         v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      }
+      if (!raw && P.resid) {
+        const float rs = P.rscale ? P.rscale[(wr0 + r + P.rs_row0) / P.rs_rows] : 1.f;
+        const float4 x4 = *reinterpret_cast<const float4*>(P.resid + (size_t)(wr0 + r) * P.ldc + wc0 + c);
+        v.x = __fadd_rn(x4.x, __fmul_rn(v.x, rs)); v.y = __fadd_rn(x4.y, __fmul_rn(v.y, rs));
+        v.z = __fadd_rn(x4.z, __fmul_rn(v.z, rs)); v.w = __fadd_rn(x4.w, __fmul_rn(v.w, rs));
       }
       *reinterpret_cast<float4*>(Cg + (size_t)(wr0 + r) * P.ldc + wc0 + c) = v;
     }
@@ -852,7 +890,7 @@ inline GemmProb make_prob(int mode, const float* A, int lda, const float* B, int
   p.A = A; p.B = B; p.C = C;
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-  p.act = ACT_NONE; p.apro = APRO_NONE; p.splitk = 1; p.store_c = 1;
+  p.act = ACT_NONE; p.apro = APRO_NONE; p.splitk = 1; p.store_c = 1; p.rs_rows = 1;
   // contiguous extent: K for k-contiguous operands, M / N otherwise
   p.a_vec = aligned16(A) && (lda % 4 == 0) && ((p.a_kc ? K : M) % 4 == 0);
   p.b_vec = aligned16(B) && (ldb % 4 == 0) && ((p.b_kc ? K : N) % 4 == 0);
