@@ -242,11 +242,18 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # PORL_BENCH_BACKEND=gloo rehearses the N>1 code path with several ranks on ONE GPU (no RCCL, no timing claim)
+    backend = os.environ.get("PORL_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from porl_amd.agent.por import POR
     from porl_amd.buffer.replay_buffer import PackedReplay
