@@ -200,6 +200,16 @@ int porl_qnet_cql_backward(porl_qnet* h, const porl_qnet_hyper* hp, void* stream
 int porl_qnet_apply(porl_qnet* h, const porl_qnet_hyper* hp, void* stream);
 int porl_qnet_learn(porl_qnet* h, const porl_qnet_hyper* hp, void* stream);   /* the two above */
 /* target_network.load_state_dict(q_network.state_dict()) */
+/* 1 when the network fits the one-launch step kernel (porl_qnet_learn_indexed and the fast path of
+ * porl_qnet_cql_backward), else 0 */
+int32_t porl_qnet_one_launch(const porl_qnet* h);
+/* learn() on the minibatch { row idx[b] (or b when idx is NULL) of the given replay arrays : b < batch } without
+ * materialising it: the gather of ReplayBuffer.sample (buffer/replay_buffer.py:64-73) happens inside the step
+ * kernel.  Only for networks the one-launch kernel covers (every layer <= 128 wide, <= 5 Linear layers);
+ * PORL_ERR_UNSUPPORTED otherwise.  actions int64, dones fp32 (1.0 = terminal). */
+int porl_qnet_learn_indexed(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions,
+                            const float* rewards, const float* next_states, int64_t n_rs, const float* dones,
+                            const int64_t* idx, int32_t batch, const porl_qnet_hyper* hp, void* stream);
 int porl_qnet_sync_target(porl_qnet* h, void* stream);
 /* q_network(states) (which=0) or target_network(states) (which=1) -> (batch, n_actions) */
 int porl_qnet_forward(porl_qnet* h, int which, const float* states, int64_t s_rs, int32_t batch,
@@ -288,9 +298,12 @@ int porl_enc_bind(porl_enc* h, float* params, float* bn_stats, float* workspace)
 int porl_enc_forward(porl_enc* h, float* state, int64_t state_rs, int32_t batch, int32_t training,
                      const float* drop_scale, float* features, int64_t feat_rs, void* stream);
 
-/* Experiment knobs (placement only, never results).  "gemm_lds_pad": extra dynamic LDS bytes per GEMM
- * block, limiting how many blocks share a CU. */
+/* Experiment knobs (scheduling only, never the mathematics).  "gemm_lds_pad": extra dynamic LDS bytes per GEMM
+ * block, limiting how many blocks share a CU.  "qnet_fused": 0 forces the multi-launch CQL path. */
 int porl_tune_set(const char* key, int value);
+/* Diagnostics taking a device pointer.  "qnet_stamps": >= 32 uint64 receiving block 0's shader-clock stamps at
+ * the phase boundaries of the one-launch CQL kernel (NULL switches it off). */
+int porl_tune_set_ptr(const char* key, void* ptr);
 
 /* Per-launch timing with HIP events on the launch stream (off by default; adds two event records per
  * kernel).  porl_prof_read synchronises the device and returns the number of entries filled. */

@@ -22,11 +22,11 @@ SYMBOLS = [
     "porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_backward",
     "porl_iql_policy_apply", "porl_iql_step", "porl_iql_forward_value", "porl_iql_forward_policy",
     "porl_gemm_f32", "porl_adam_ema", "porl_gather_rows", "porl_sample_indices",
-    "porl_prof_enable", "porl_prof_read", "porl_tune_set", "porl_state2costmap",
+    "porl_prof_enable", "porl_prof_read", "porl_tune_set", "porl_tune_set_ptr", "porl_state2costmap",
     "porl_qnet_create", "porl_qnet_destroy", "porl_qnet_param_floats", "porl_qnet_tensors",
     "porl_qnet_tensor_info", "porl_qnet_workspace_floats", "porl_qnet_bind", "porl_qnet_load_batch",
     "porl_qnet_cql_backward", "porl_qnet_apply", "porl_qnet_learn", "porl_qnet_sync_target",
-    "porl_qnet_forward", "porl_qnet_penalty",
+    "porl_qnet_forward", "porl_qnet_penalty", "porl_qnet_learn_indexed", "porl_qnet_one_launch",
     "porl_enc_create", "porl_enc_destroy", "porl_enc_param_floats", "porl_enc_stat_floats",
     "porl_enc_workspace_floats", "porl_enc_tensors", "porl_enc_norms", "porl_enc_blocks",
     "porl_enc_tensor_info", "porl_enc_norm_info", "porl_enc_bind", "porl_enc_forward",
@@ -113,6 +113,7 @@ def _declare(lib):
     lib.porl_gather_rows.argtypes = [vp, i64, vp, i32, i32, vp, i64, vp]
     lib.porl_sample_indices.argtypes = [i64, i32, C.c_uint64, C.c_uint64, i64, vp, vp]
     lib.porl_tune_set.argtypes = [C.c_char_p, C.c_int]
+    lib.porl_tune_set_ptr.argtypes = [C.c_char_p, vp]
     lib.porl_state2costmap.argtypes = [vp, i64, i32, i32, i32, vp, vp]
     lib.porl_qnet_create.argtypes = [C.POINTER(QnetCfg), C.POINTER(vp)]
     lib.porl_qnet_destroy.argtypes = [vp]
@@ -128,6 +129,9 @@ def _declare(lib):
     lib.porl_qnet_load_batch.argtypes = [vp, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp]
     for name in ("porl_qnet_cql_backward", "porl_qnet_apply", "porl_qnet_learn"):
         getattr(lib, name).argtypes = [vp, C.POINTER(QnetHyper), vp]
+    lib.porl_qnet_learn_indexed.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, i32, C.POINTER(QnetHyper), vp]
+    lib.porl_qnet_one_launch.argtypes = [vp]
+    lib.porl_qnet_one_launch.restype = i32
     lib.porl_qnet_sync_target.argtypes = [vp, vp]
     lib.porl_qnet_forward.argtypes = [vp, C.c_int, vp, i64, i32, vp, i64, vp]
     lib.porl_qnet_penalty.argtypes = [vp, vp, i64, vp, i64, i32, vp, vp]

@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "porl_api.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("gemm_f32.hpp", "kernels.hpp", "encoder.hpp", "encoder_api.inc")] + \
+DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))) + \
        [os.path.join(os.path.dirname(HERE), "include", "porl_hip.h")]
 OUT = os.path.join(HERE, "lib", "libporl_hip.so")
 

@@ -13,6 +13,7 @@
 #include "../../include/porl_hip.h"
 #include "gemm_f32.hpp"
 #include "kernels.hpp"
+#include "qnet_fused.hpp"
 
 using namespace porl;
 
@@ -76,6 +77,9 @@ struct ProfScope {
     g_prof.recs.push_back(r);
   }
 };
+
+unsigned long long* g_qnet_stamps = nullptr;   // porl_tune_set_ptr("qnet_stamps", device buffer of >= 32 u64)
+int g_qnet_fused = 1;     // porl_tune_set("qnet_fused", 0) forces the multi-launch CQL path (A/B measurements)
 
 constexpr int NUM_CU = 256;
 constexpr int SK_MAX = 16;
@@ -943,6 +947,13 @@ int porl_sample_indices(int64_t n_rows, int32_t batch, uint64_t seed, uint64_t s
 int porl_tune_set(const char* key, int value) {
   if (!key) PORL_FAIL(PORL_ERR_INVALID, "null key");
   if (!strcmp(key, "gemm_lds_pad")) { gemm_lds_pad() = std::max(0, value); return PORL_OK; }
+  if (!strcmp(key, "qnet_fused")) { g_qnet_fused = value != 0; return PORL_OK; }
+  PORL_FAIL(PORL_ERR_INVALID, "unknown tuning key '%s'", key);
+}
+
+int porl_tune_set_ptr(const char* key, void* ptr) {
+  if (!key) PORL_FAIL(PORL_ERR_INVALID, "null key");
+  if (!strcmp(key, "qnet_stamps")) { g_qnet_stamps = (unsigned long long*)ptr; return PORL_OK; }
   PORL_FAIL(PORL_ERR_INVALID, "unknown tuning key '%s'", key);
 }
 
@@ -1010,9 +1021,16 @@ struct porl_qnet {
   int Sp = 0, Ap = 0, ld[PORL_MAX_HIDDEN + 2] = {0};     // padded leading dims per layer output
   struct {
     int64_t xs, xn, rew, done, actions;                  // actions: int64 stored in 2 floats each
-    int64_t act[PORL_MAX_HIDDEN + 1], tmp[2], dz[2], slab, part_td, part_pen, total;
+    int64_t act[PORL_MAX_HIDDEN + 1], tmp[2], dz[2], slab, part_td, part_pen, fslab, total;
   } ws;
+  // one-launch path (qnet_fused.hpp): every width <= 128, at most QF_MAX_LIN Linear layers, LDS plan fits
+  bool fused_ok = false;
+  QnetFusedArgs fargs{};
+  int fused_lds_bytes = 0;
+  int64_t fslab_stride = 0;
+  bool fslab_clean = false;          // alignment gaps of the flat layout are never written: zeroed once
 };
+
 
 extern "C" {
 
@@ -1050,8 +1068,36 @@ int porl_qnet_create(const porl_qnet_cfg* c, porl_qnet** out) {
   h->ws.tmp[0] = take((int64_t)B * maxld); h->ws.tmp[1] = take((int64_t)B * maxld);
   h->ws.dz[0] = take((int64_t)B * maxld); h->ws.dz[1] = take((int64_t)B * maxld);
   h->ws.slab = take((int64_t)SK_MAX * (cur + 64));
-  const int nblk = cdiv(B, 256);
+  const int nblk = cdiv(B, QF_ROWS);
   h->ws.part_td = take(nblk); h->ws.part_pen = take(nblk);
+  {
+    // LDS plan of the fused kernel
+    bool ok = (L + 1 <= QF_MAX_LIN);
+    int maxw = 0, wmax = 0;
+    for (int l = 0; l <= L + 1 && ok; ++l) { ok = m.dims[l] <= QF_MAX_W; maxw = std::max(maxw, (m.dims[l] + 31) & ~31); }
+    QnetFusedArgs& fa = h->fargs;
+    int off = 0;
+    if (ok) {
+      fa.n_lin = L + 1;
+      for (int l = 0; l <= L + 1; ++l) {
+        fa.dims[l] = m.dims[l];
+        fa.lds_act[l] = off;
+        off += QF_ROWS * (((m.dims[l] + 31) & ~31) + 4);
+      }
+      for (int l = 0; l <= L; ++l) {
+        fa.w_off[l] = m.w[l]; fa.b_off[l] = m.b[l];
+        wmax = std::max(wmax, ((m.dims[l + 1] + 31) & ~31) * (((m.dims[l] + 3) & ~3) + 4));
+      }
+      fa.lds_tmp[0] = off; off += QF_ROWS * (maxw + 4);
+      fa.lds_tmp[1] = off; off += QF_ROWS * (maxw + 4);
+      fa.lds_w = off; off += wmax + 32;
+      ok = off * (int)sizeof(float) <= QF_MAX_LDS_BYTES;
+    }
+    h->fused_ok = ok;
+    h->fused_lds_bytes = off * (int)sizeof(float);
+    h->fslab_stride = ru4(cur);
+    h->ws.fslab = ok ? take((int64_t)nblk * h->fslab_stride) : 0;
+  }
   h->ws.total = o;
   *out = h;
   return PORL_OK;
@@ -1068,6 +1114,7 @@ int porl_qnet_tensor_info(const porl_qnet* h, int index, int64_t* offset, int32_
   return PORL_OK;
 }
 int64_t porl_qnet_workspace_floats(const porl_qnet* h) { return h ? h->ws.total : 0; }
+int32_t porl_qnet_one_launch(const porl_qnet* h) { return h && h->fused_ok && g_qnet_fused ? 1 : 0; }
 
 int porl_qnet_bind(porl_qnet* h, const porl_qnet_buffers* b) {
   if (!h || !b) PORL_FAIL(PORL_ERR_INVALID, "null argument");
@@ -1079,6 +1126,7 @@ int porl_qnet_bind(porl_qnet* h, const porl_qnet_buffers* b) {
   h->buf = *b;
   h->bound = true;
   h->batch = 0;
+  h->fslab_clean = false;
   return PORL_OK;
 }
 
@@ -1140,12 +1188,67 @@ static int qnet_forward(porl_qnet* h, int nnets, const float* const* params, con
   return PORL_OK;
 }
 
+// gradient of one minibatch in two launches: the fused step kernel (32 rows per block), then the block-order
+// sum of the partial gradients (+ loss statistics)
+static int qnet_fused_backward(porl_qnet* h, const porl_qnet_hyper* hp, int B, const float* states, int64_t s_rs,
+                               const float* next_states, int64_t n_rs, const int64_t* actions, const float* rew,
+                               const float* done, const int64_t* idx, hipStream_t s, bool with_adam = false) {
+  float* W = h->buf.workspace;
+  QnetFusedArgs a = h->fargs;
+  a.params = h->buf.params; a.params_tgt = h->buf.params_tgt;
+  a.states = states; a.s_rs = s_rs; a.next_states = next_states; a.n_rs = n_rs;
+  a.actions = actions; a.rew = rew; a.done = done; a.idx = idx;
+  a.slab = W + h->ws.fslab; a.slab_stride = h->fslab_stride;
+  a.part_td = W + h->ws.part_td; a.part_pen = W + h->ws.part_pen;
+  a.B = B;
+  a.gamma = hp->gamma; a.alpha = hp->alpha; a.inv_batch = hp->inv_batch;
+  a.log_A = (float)std::log((double)h->cfg.n_actions);
+  a.stamps = g_qnet_stamps;
+  static bool attr_set = false;
+  if (!attr_set) {
+    PORL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 QF_MAX_LDS_BYTES));
+    attr_set = true;
+  }
+  const int nblk = cdiv(B, QF_ROWS);
+  if (!h->fslab_clean) {
+    PORL_HIP(hipMemsetAsync(W + h->ws.fslab, 0, sizeof(float) * cdiv(h->cfg.max_batch, QF_ROWS) * h->fslab_stride, s));
+    h->fslab_clean = true;
+  }
+  {
+    double macs = 0;
+    for (int l = 0; l < a.n_lin; ++l) macs += (double)a.dims[l] * a.dims[l + 1];
+    ProfScope ps("qnet_fused_kernel", s, 2.0 * B * macs * 4.0, 8.0 * B * a.dims[0]);
+    hipLaunchKernelGGL(qnet_fused_kernel, dim3(nblk), dim3(256), (size_t)h->fused_lds_bytes, s, a);
+    PORL_HIP(hipGetLastError());
+  }
+  QnetAdam ad{};
+  if (with_adam) {
+    if (hp->step < 1) PORL_FAIL(PORL_ERR_INVALID, "adam step must be >= 1");
+    // the scalars of adam_launch: python doubles, rounded to fp32 where they meet tensors
+    ad.p = h->buf.params; ad.m = h->buf.adam_m; ad.v = h->buf.adam_v;
+    ad.omb1 = (float)(1.0 - hp->adam_beta1); ad.beta2 = (float)hp->adam_beta2; ad.omb2 = (float)(1.0 - hp->adam_beta2);
+    ad.eps = (float)hp->adam_eps;
+    ad.step_size = (float)(hp->lr / (1.0 - std::pow(hp->adam_beta1, (double)hp->step)));
+    ad.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(hp->adam_beta2, (double)hp->step));
+  }
+  ProfScope ps(with_adam ? "qnet_reduce_kernel+adam" : "qnet_reduce_kernel", s, 0.0, 4.0 * nblk * h->n_params);
+  hipLaunchKernelGGL(qnet_reduce_kernel, dim3(cdiv((int)h->n_params, 32)), dim3(256), 0, s, W + h->ws.fslab, (long)h->fslab_stride,
+                     nblk, (long)h->n_params, h->buf.grads, W + h->ws.part_td, W + h->ws.part_pen, hp->inv_batch, hp->alpha,
+                     h->buf.stats, ad);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
 int porl_qnet_cql_backward(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
   PORL_TRY(qnet_ready(h, true));
   if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
   hipStream_t s = (hipStream_t)stream;
   const int B = h->batch, L = h->cfg.n_hidden, A = h->cfg.n_actions;
   float* W = h->buf.workspace;
+  if (h->fused_ok && g_qnet_fused)
+    return qnet_fused_backward(h, hp, B, W + h->ws.xs, h->Sp, W + h->ws.xn, h->Sp,
+                               reinterpret_cast<const int64_t*>(W + h->ws.actions), W + h->ws.rew, W + h->ws.done, nullptr, s);
   // forward: target net on s' (activations ping-pong in tmp), online net on s (activations kept)
   float* dst[2][PORL_MAX_HIDDEN + 1];
   for (int l = 0; l <= L; ++l) { dst[0][l] = W + h->ws.tmp[l & 1]; dst[1][l] = W + h->ws.act[l]; }
@@ -1214,8 +1317,29 @@ int porl_qnet_apply(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
 }
 
 int porl_qnet_learn(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
+  PORL_TRY(qnet_ready(h, true));
+  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+  if (h->fused_ok && g_qnet_fused) {
+    float* W = h->buf.workspace;
+    return qnet_fused_backward(h, hp, h->batch, W + h->ws.xs, h->Sp, W + h->ws.xn, h->Sp,
+                               reinterpret_cast<const int64_t*>(W + h->ws.actions), W + h->ws.rew, W + h->ws.done, nullptr,
+                               (hipStream_t)stream, true);
+  }
   PORL_TRY(porl_qnet_cql_backward(h, hp, stream));
   return porl_qnet_apply(h, hp, stream);
+}
+
+int porl_qnet_learn_indexed(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions, const float* rewards,
+                            const float* next_states, int64_t n_rs, const float* dones, const int64_t* idx, int32_t batch,
+                            const porl_qnet_hyper* hp, void* stream) {
+  PORL_TRY(qnet_ready(h, false));
+  if (!hp || !states || !actions || !rewards || !next_states || !dones) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
+  if (!h->fused_ok || !g_qnet_fused)
+    PORL_FAIL(PORL_ERR_UNSUPPORTED, "the one-launch path needs every layer <= %d wide and <= %d Linear layers; gather the "
+              "minibatch and use porl_qnet_load_batch + porl_qnet_learn", QF_MAX_W, QF_MAX_LIN);
+  return qnet_fused_backward(h, hp, batch, states, s_rs, next_states, n_rs, actions, rewards, dones, idx,
+                             (hipStream_t)stream, true);
 }
 
 int porl_qnet_sync_target(porl_qnet* h, void* stream) {

@@ -1,0 +1,379 @@
+// One-launch CQL(H) gradient for small Q-networks (reference src/porl/train/cql_trainer.py:88-124, config 3:
+// 60 -> 64 -> 128 -> 64 -> 10 at batch 4096).  Every layer is at most 128 wide, so a block keeps 32 minibatch
+// rows, one layer's weights and all activations of those rows in LDS and walks the whole step itself:
+//   target net on s' -> online net on s -> TD target, logsumexp penalty, dL/dQ -> backward through the layers.
+// The multi-launch path (porl_api.hip) spends ~7 us per dependent launch on ~20 launches of a few us each; this
+// kernel is latency-bound inside one block instead.  Matrix work runs on v_mfma_f32_32x32x2_f32 (exact fp32
+// fmaf chains): forward and dgrad tiles are 32 rows x 32 columns per wave, wgrad tiles 32 x 32 of dW per wave
+// with the 32 rows as the reduction.  Per-block partial gradients go to a slab in the flat parameter layout
+// and are summed in block order by qnet_reduce_kernel (deterministic).
+//
+// LDS images are row-major with stride = width + 4 floats (16-byte rows, conflict-free 8-byte fragment reads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace porl {
+
+constexpr int QF_ROWS = 32;          // minibatch rows per block = one MFMA tile
+constexpr int QF_MAX_LIN = 5;        // Linear layers (hidden + output)
+constexpr int QF_MAX_W = 128;        // widest layer
+constexpr int QF_MAX_LDS_BYTES = 160 * 1024 - 1024;  // dynamic LDS budget (the kernel also has ~0.5 KB of static LDS)
+
+struct QnetFusedArgs {
+  const float* params;               // online, flat (W (out,in) row-major then bias, per layer)
+  const float* params_tgt;
+  // minibatch source: row b of the batch is row idx[b] (or b when idx is null) of these arrays
+  const float* states; long s_rs;
+  const float* next_states; long n_rs;
+  const int64_t* actions; const float* rew; const float* done;
+  const int64_t* idx;
+  float* slab; long slab_stride;     // (blocks, slab_stride): partial gradients, flat parameter layout
+  float* part_td; float* part_pen;   // (blocks,)
+  int B, n_lin;
+  int dims[QF_MAX_LIN + 1];          // dims[0] = state_dim, dims[n_lin] = n_actions
+  long w_off[QF_MAX_LIN], b_off[QF_MAX_LIN];
+  // LDS offsets (floats), strides = round32(width) + 4
+  int lds_act[QF_MAX_LIN + 1];       // lds_act[0] = input rows, lds_act[l + 1] = output of layer l (online net)
+  int lds_tmp[2];                    // ping-pong: target-net activations, then dZ
+  int lds_w;                         // one layer's weights, (round32(out), round4(in) + 4)
+  float gamma, alpha, inv_batch, log_A;
+  unsigned long long* stamps;        // diagnostics: shader-clock stamps of block 0 at the phase boundaries, or null
+};
+
+typedef float qf_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int qf_r32(int x) { return (x + 31) & ~31; }
+__device__ __forceinline__ int qf_r4(int x) { return (x + 3) & ~3; }
+// i / d for 0 <= i < 2^16, 1 <= d <= 256 in three instructions (the half-unit margin dwarfs fp32 rounding)
+__device__ __forceinline__ int qf_div(int i, float inv_d) { return __float2int_rz(((float)i + 0.5f) * inv_d); }
+
+// Minibatch rows of s' and s -> LDS [32][ld] each, zero padded (columns and rows past B).  The source row numbers
+// are read first (one round trip), then every element of both inputs is requested before the first LDS store.
+constexpr int QF_XREGS = (QF_ROWS * (QF_MAX_W + 4) + 255) / 256;      // 17
+__device__ __forceinline__ void qf_load_inputs(float* dst_n, float* dst_s, int ld, const float* next_states, long n_rs,
+                                               const float* states, long s_rs, const int64_t* idx, int row0, int B,
+                                               int cols, int t) {
+  const int total = QF_ROWS * ld;
+  const float inv_ld = 1.0f / (float)ld;
+  float vn[QF_XREGS], vs[QF_XREGS];
+#pragma unroll
+  for (int u = 0; u < QF_XREGS; ++u) {
+    if (u * 256 < total) {                            // uniform
+      const int i = u * 256 + t;
+      const int r = qf_div(i, inv_ld), c = i - r * ld;
+      const int b = row0 + r;
+      const bool ok = i < total && b < B && c < cols;
+      const long row = idx ? idx[b < B ? b : 0] : (long)b;
+      const float xn = next_states[ok ? row * n_rs + c : 0L];
+      const float xs = states[ok ? row * s_rs + c : 0L];
+      vn[u] = ok ? xn : 0.f;
+      vs[u] = ok ? xs : 0.f;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < QF_XREGS; ++u) {
+    const int i = u * 256 + t;
+    if (u * 256 < total && i < total) { dst_n[i] = vn[u]; dst_s[i] = vs[u]; }
+  }
+}
+
+// One layer's weights (N, K) -> LDS [round32(N)][round4(K) + 4], zero padded, in two halves: qf_fetch_w requests
+// them into registers (16-byte loads when rows allow; QF_WREGS float4 per thread cover 128 x 128), qf_park_w
+// writes them to LDS.  The kernel fetches layer j+1 before it computes layer j, so the round trip to L2 hides
+// behind the MFMA work of the previous layer.
+constexpr int QF_WREGS = (QF_MAX_W * (QF_MAX_W + 4) / 4 + 255) / 256;      // 17
+__device__ __forceinline__ void qf_fetch_w(float4 (&v)[QF_WREGS], float& bias_reg, const float* W, const float* bias, int N,
+                                           int K, int t) {
+  const int ld4 = (qf_r4(K) + 4) >> 2, total4 = qf_r32(N) * ld4;
+  const float inv_ld4 = 1.0f / (float)ld4;
+  const bool vec = (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0);
+  // branch-free: every lane loads from a valid address and the result is selected afterwards — a branch around
+  // a load makes the compiler drain vmcnt at the join, which would serialise the 17 requests
+  const float bv = bias[t < N ? t : 0];
+  bias_reg = t < N ? bv : 0.f;                       // N <= 128 < 256 threads
+  if (vec) {
+#pragma unroll
+    for (int u = 0; u < QF_WREGS; ++u) {
+      if (u * 256 >= total4) continue;               // uniform: small layers use few slots
+      const int i = u * 256 + t;
+      const int n = qf_div(i, inv_ld4), k = (i - n * ld4) << 2;
+      const bool ok = i < total4 && n < N && k < K;
+      const float4 x = *reinterpret_cast<const float4*>(W + (ok ? n * K + k : 0));
+      v[u] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < QF_WREGS; ++u) {
+      if (u * 256 >= total4) continue;
+      const int i = u * 256 + t;
+      const int n = qf_div(i, inv_ld4), k = (i - n * ld4) << 2;
+      const bool ok = i < total4 && n < N;
+      const float* p = W + (ok ? (long)n * K : 0L);
+      const float x0 = p[k < K ? k : 0], x1 = p[k + 1 < K ? k + 1 : 0], x2 = p[k + 2 < K ? k + 2 : 0],
+                  x3 = p[k + 3 < K ? k + 3 : 0];
+      v[u] = make_float4(ok && k < K ? x0 : 0.f, ok && k + 1 < K ? x1 : 0.f, ok && k + 2 < K ? x2 : 0.f,
+                         ok && k + 3 < K ? x3 : 0.f);
+    }
+  }
+}
+__device__ __forceinline__ void qf_park_w(float* wl, float* bl, const float4 (&v)[QF_WREGS], float bias_reg, int N, int K,
+                                          int t) {
+  const int total4 = qf_r32(N) * ((qf_r4(K) + 4) >> 2);
+  if (t < QF_MAX_W) bl[t] = bias_reg;
+#pragma unroll
+  for (int u = 0; u < QF_WREGS; ++u) {
+    const int i = u * 256 + t;
+    if (i < total4) reinterpret_cast<float4*>(wl)[i] = v[u];
+  }
+}
+
+// out[32][ldo] = act(in[32][ldi] . Wl^T + bias): wave w computes the 32-column slabs w, w+4, ...
+__device__ __forceinline__ void qf_forward(const float* in, int ldi, const float* wl, int K, int N, const float* bias /* LDS */,
+                                           bool relu, float* out, int ldo, int wave, int li, int kh) {
+  const int ldw = qf_r4(K) + 4, Kp = qf_r4(K);
+  for (int tn = wave; tn < qf_r32(N) / 32; tn += 4) {
+    qf_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* ap = in + li * ldi + 2 * kh;
+    const float* bp = wl + (tn * 32 + li) * ldw + 2 * kh;
+    float2 a = *reinterpret_cast<const float2*>(ap), b = *reinterpret_cast<const float2*>(bp);
+    for (int k0 = 0; k0 < Kp; k0 += 4) {
+      // the rows have 4 floats of slack, so reading one step past the end stays inside the image
+      const float2 an = *reinterpret_cast<const float2*>(ap + k0 + 4);
+      const float2 bn = *reinterpret_cast<const float2*>(bp + k0 + 4);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      a = an; b = bn;
+    }
+    const int col = tn * 32 + li;
+    const float bv = bias[col];                    // zero past N
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[r] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      if (col >= N) v = 0.f;
+      out[((r & 3) + 8 * (r >> 2) + 4 * kh) * ldo + col] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) {
+  extern __shared__ float qf_lds[];
+  __shared__ float red[2];
+  __shared__ float bl[QF_MAX_W];                     // bias of the layer whose weights sit in wl
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, kh = lane >> 5;
+  const int row0 = blockIdx.x * QF_ROWS;
+  const int L = a.n_lin - 1;
+  float* wl = qf_lds + a.lds_w;
+  float* X = qf_lds + a.lds_act[0];
+  const int ldx = qf_r32(a.dims[0]) + 4;
+
+  // Weight pipeline: stage j = target layer j (j <= L), online layer j-L-1 (j <= 2L+1), then the online layers
+  // L..1 again for the backward pass.  Stage j+1 is requested into registers right after stage j is parked in LDS.
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if (a.stamps && blockIdx.x == 0 && t == 0) a.stamps[n_stamp++] = __builtin_amdgcn_s_memtime();
+  };
+  stamp();
+  float4 wr[QF_WREGS];
+  float br = 0.f;
+  auto stage = [&](int j, const float*& W, const float*& bias, int& N, int& K) {
+    const int l = j <= L ? j : (j <= 2 * L + 1 ? j - L - 1 : 3 * L + 2 - j);
+    const float* P = j <= L ? a.params_tgt : a.params;
+    W = P + a.w_off[l]; bias = P + a.b_off[l];
+    N = a.dims[l + 1]; K = a.dims[l];
+  };
+  auto fetch = [&](int j) {
+    if (j > 3 * L + 1) return;
+    const float* W; const float* bias; int N, K;
+    stage(j, W, bias, N, K);
+    qf_fetch_w(wr, br, W, bias, N, K, t);
+  };
+  auto park = [&](int j) {
+    const float* W; const float* bias; int N, K;
+    stage(j, W, bias, N, K);
+    qf_park_w(wl, bl, wr, br, N, K, t);
+  };
+  fetch(0);
+
+  // ---- target network on s'  (cql_trainer.py:99-101) ---------------------------------------------------
+  // s' waits in tmp[1] (free until the target net's layer 1 writes there), s in the online net's input buffer
+  float* Xn = qf_lds + a.lds_tmp[1];
+  qf_load_inputs(Xn, X, ldx, a.next_states, a.n_rs, a.states, a.s_rs, a.idx, row0, a.B, a.dims[0], t);
+  for (int l = 0; l <= L; ++l) {
+    park(l);
+    __syncthreads();
+    fetch(l + 1);
+    const float* in = l == 0 ? Xn : qf_lds + a.lds_tmp[(l - 1) & 1];
+    qf_forward(in, qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L,
+               qf_lds + a.lds_tmp[l & 1], qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
+    __syncthreads();
+  }
+  stamp();
+  const float* Qn = qf_lds + a.lds_tmp[L & 1];
+  float* dz = qf_lds + a.lds_tmp[(L + 1) & 1];
+
+  // ---- online network on s, activations kept ------------------------------------------------------------
+  for (int l = 0; l <= L; ++l) {
+    park(L + 1 + l);
+    __syncthreads();
+    fetch(L + 2 + l);
+    qf_forward(qf_lds + a.lds_act[l], qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L,
+               qf_lds + a.lds_act[l + 1], qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
+    __syncthreads();
+  }
+
+  stamp();
+  // ---- loss and dL/dQ: one lane per row  (cql_trainer.py:94-118; same arithmetic as cql_loss_kernel) ----
+  const int A = a.dims[L + 1], ldq = qf_r32(A) + 4;
+  if (wave == 0) {
+    float td = 0.f, pen = 0.f;
+    if (lane < QF_ROWS) {
+      const int b = row0 + lane;
+      float* dq = dz + lane * ldq;
+      if (b < a.B) {
+        const float* q = qf_lds + a.lds_act[L + 1] + lane * ldq;
+        const float* qn = Qn + lane * ldq;
+        float mx = -INFINITY, mxn = -INFINITY;
+        for (int j = 0; j < A; ++j) { mx = fmaxf(mx, q[j]); mxn = fmaxf(mxn, qn[j]); }
+        float se = 0.f;
+        for (int j = 0; j < A; ++j) se += expf(q[j] - mx);
+        const float lse = mx + logf(se);
+        const long src = a.idx ? a.idx[b] : (long)b;
+        const int act = (int)a.actions[src];
+        const float qa = q[act];
+        const float y = a.rew[src] + a.gamma * mxn * (1.f - a.done[src]);
+        const float diff = qa - y;
+        td = diff * diff;
+        pen = lse - a.log_A - qa;
+        const float ab = a.alpha * a.inv_batch;
+        for (int j = 0; j < A; ++j) {
+          float g = ab * expf(q[j] - lse);
+          if (j == act) g += 2.f * a.inv_batch * diff - ab;
+          dq[j] = g;
+        }
+        for (int j = A; j < ldq; ++j) dq[j] = 0.f;
+      } else {
+        for (int j = 0; j < ldq; ++j) dq[j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { td += __shfl_xor(td, o); pen += __shfl_xor(pen, o); }
+    if (lane == 0) { red[0] = td; red[1] = pen; }
+  }
+  __syncthreads();
+  if (t == 0) { a.part_td[blockIdx.x] = red[0]; a.part_pen[blockIdx.x] = red[1]; }
+  stamp();
+
+  // ---- backward, top down ----------------------------------------------------------------------------------
+  float* slab = a.slab + (long)blockIdx.x * a.slab_stride;
+  for (int l = L; l >= 0; --l) {
+    const int N = a.dims[l + 1], K = a.dims[l];
+    const int lddz = qf_r32(N) + 4, ldin = qf_r32(K) + 4;
+    const float* in = qf_lds + a.lds_act[l];
+    if (l > 0) park(3 * L + 2 - l);                                   // for dZ_{l-1}; nobody reads wl right now
+    // dW_l = dZ^T . in over the block's 32 rows: tiles of 32 (n) x 32 (k), round-robin over the waves
+    const int tiles_n = qf_r32(N) / 32, tiles_k = qf_r32(K) / 32;
+    for (int tile = wave; tile < tiles_n * tiles_k; tile += 4) {
+      const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+      qf_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int s2 = 0; s2 < QF_ROWS / 2; ++s2) {
+        const int row = 2 * s2 + kh;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[row * lddz + tn * 32 + li], in[row * ldin + tk * 32 + li], acc, 0, 0, 0);
+      }
+      const int k = tk * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (n < N && k < K) slab[a.w_off[l] + (long)n * K + k] = acc[r];
+      }
+    }
+    // db_l = column sums of dZ
+    for (int n = t; n < N; n += 256) {
+      float s = 0.f;
+      for (int r = 0; r < QF_ROWS; ++r) s += dz[r * lddz + n];
+      slab[a.b_off[l] + n] = s;
+    }
+    stamp();
+    if (l == 0) break;
+    __syncthreads();                                                  // wl is parked
+    fetch(3 * L + 3 - l);
+    // dZ_{l-1} = (dZ . W_l) * 1[in > 0]: 32-column slabs of K over the waves
+    float* dzp = qf_lds + a.lds_tmp[l & 1];                           // dZ_l lives in tmp[(l + 1) & 1]
+    const int ldw = qf_r4(K) + 4;
+    for (int tk = wave; tk < tiles_k; tk += 4) {
+      qf_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int n0 = 0; n0 < qf_r32(N); n0 += 2) {
+        const int n = n0 + kh;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[li * lddz + n], wl[n * ldw + tk * 32 + li], acc, 0, 0, 0);
+      }
+      const int col = tk * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        dzp[row * ldin + col] = (col < K && in[row * ldin + col] > 0.f) ? acc[r] : 0.f;
+      }
+    }
+    __syncthreads();
+    dz = dzp;
+    stamp();
+  }
+}
+
+// optional Adam step fused into the gradient reduction (p == null: off)
+struct QnetAdam { float* p; float* m; float* v; float omb1, beta2, omb2, eps, step_size, bc2_sqrt; };
+
+// grads[i] = sum over blocks of slab[b][i], in a fixed order: 32 parameters x 8 slab lanes per block, lane j adds
+// slabs j, j+8, ... and the 8 lane sums are added in lane order.  Block 0 also folds the loss partials into
+// stats[0] = loss, [1] = td, [2] = penalty (this rank's shares, like cql_finalize_kernel).
+__global__ __launch_bounds__(256) void qnet_reduce_kernel(const float* __restrict__ slab, long stride, int nblocks, long n,
+                                                          float* __restrict__ grads, const float* __restrict__ part_td,
+                                                          const float* __restrict__ part_pen, float inv_batch, float alpha,
+                                                          float* __restrict__ stats, QnetAdam ad) {
+  __shared__ float part[8][32];
+  const int c = threadIdx.x & 31, j = threadIdx.x >> 5;
+  const long i = (long)blockIdx.x * 32 + c;
+  float s = 0.f;
+  if (i < n) {
+    for (int b0 = j; b0 < nblocks; b0 += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = b0 + 8 * u < nblocks ? slab[(long)(b0 + 8 * u) * stride + i] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+  }
+  part[j][c] = s;
+  __syncthreads();
+  if (j == 0 && i < n) {
+    float r = part[0][c];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r += part[k][c];
+    grads[i] = r;
+    if (ad.p) {       // torch.optim.Adam, the arithmetic of adam_ema_kernel (kernels.hpp)
+      float mm = ad.m[i], vv = ad.v[i], pp = ad.p[i];
+      mm = mm + ad.omb1 * (r - mm);
+      vv = vv * ad.beta2 + ad.omb2 * r * r;
+      pp = pp - ad.step_size * (mm / (sqrtf(vv) / ad.bc2_sqrt + ad.eps));
+      ad.m[i] = mm; ad.v[i] = vv; ad.p[i] = pp;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    float td = 0.f, pen = 0.f;
+    for (int k = threadIdx.x; k < nblocks; k += 64) { td += part_td[k]; pen += part_pen[k]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { td += __shfl_xor(td, o); pen += __shfl_xor(pen, o); }
+    if (threadIdx.x == 0) {
+      td *= inv_batch; pen *= inv_batch;
+      stats[0] = td + alpha * pen; stats[1] = td; stats[2] = pen;
+    }
+  }
+}
+
+}  // namespace porl

@@ -43,6 +43,11 @@ class QnetEngine:
         self.stats = torch.zeros(8, dtype=torch.float32, device=self.device)
         self.workspace, self._bound = None, False
 
+    @property
+    def fused(self):
+        """True when the network fits the one-launch step kernel (csrc/qnet_fused.hpp)."""
+        return bool(self._lib.porl_qnet_one_launch(self._h))
+
     def tensor_table(self):
         out = []
         off, r, c = C.c_int64(), C.c_int32(), C.c_int32()
@@ -98,6 +103,25 @@ class QnetEngine:
     def cql_backward(self, hp): N.check(self._lib.porl_qnet_cql_backward(self._h, C.byref(hp), N.current_stream_ptr()), "porl_qnet_cql_backward")
     def apply(self, hp): N.check(self._lib.porl_qnet_apply(self._h, C.byref(hp), N.current_stream_ptr()), "porl_qnet_apply")
     def learn(self, hp): N.check(self._lib.porl_qnet_learn(self._h, C.byref(hp), N.current_stream_ptr()), "porl_qnet_learn")
+
+    def learn_indexed(self, hp, states, actions, rewards, next_states, dones, idx):
+        """learn() on rows `idx` (int64, device) of device-resident replay arrays, gathered inside the step kernel.
+        Raises NativeError(PORL_ERR_UNSUPPORTED) for networks the one-launch kernel does not cover."""
+        self._ensure_bound()
+        B = idx.numel()
+        if B > self.cfg.max_batch:
+            raise RuntimeError(f"batch {B} exceeds engine max_batch {self.cfg.max_batch}")
+        for name, x, dt in (("states", states, torch.float32), ("next_states", next_states, torch.float32),
+                            ("actions", actions, torch.int64), ("rewards", rewards, torch.float32),
+                            ("dones", dones, torch.float32), ("idx", idx, torch.int64)):
+            if x.dtype != dt or x.device != self.device or not x.is_contiguous():
+                raise RuntimeError(f"{name}: need a contiguous {dt} tensor on {self.device}")
+        if states.shape[1:].numel() != self.cfg.state_dim or next_states.shape != states.shape:
+            raise RuntimeError("replay arrays do not match the network's state_dim")
+        N.check(self._lib.porl_qnet_learn_indexed(self._h, N.ptr(states), self.cfg.state_dim, N.ptr(actions), N.ptr(rewards),
+                                                  N.ptr(next_states), self.cfg.state_dim, N.ptr(dones), N.ptr(idx), B,
+                                                  C.byref(hp), N.current_stream_ptr()), "porl_qnet_learn_indexed")
+        return B
 
     def sync_target(self):
         self._ensure_bound()
@@ -220,7 +244,20 @@ class CQLTrainer:
         self._draws = getattr(self, "_draws", 0)
         idx = E.sample_indices(rb.size, self.batch_size, seed, self._draws, device=self.device)
         self._draws += 1
-        return self.learn_on(*rb.gather_device(idx))
+        eng, ex = self._engine, self._exchange
+        if ex.world_size > 1 or not eng.fused:
+            return self.learn_on(*rb.gather_device(idx))
+        # one-launch path: the step kernel gathers rows idx of the device mirror itself
+        m = rb._mirror
+        self.optimizer.step_count += 1
+        g = self.optimizer.param_groups[0]
+        hp = eng.hyper(self.gamma, float(self.alpha), 1.0 / idx.numel(), self.optimizer.step_count, g["lr"], g["betas"],
+                       g["eps"])
+        eng.learn_indexed(hp, m["states"], m["actions"], m["rewards"], m["next_states"], m["dones"], idx)
+        if self.async_losses:
+            return eng.stats[:3]
+        loss, self.last_td_loss, self.last_cql_penalty = eng.stats[:3].tolist()
+        return loss
 
     def compute_cql_penalty(self, states, actions):
         return self._engine.penalty(states, actions)

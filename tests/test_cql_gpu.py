@@ -97,3 +97,84 @@ def test_replay_buffer_sample_matches_reference_stream():
     rb.push(st[0] + 1, 3, 2.5, ns[0], True)
     s, a, r, n, d = rb.sample_at(np.array([(rb.position - 1) % cap]))
     assert np.array_equal(s.cpu().numpy()[0], st[0] + 1) and int(a) == 3 and float(r) == 2.5 and float(d) == 1.0
+
+
+@pytest.mark.parametrize("S,A,B,hidden", [(60, 10, 4096, None), (8, 4, 50, None)])
+def test_one_launch_step_matches_the_multi_launch_path(S, A, B, hidden):
+    """csrc/qnet_fused.hpp (32 rows per block, everything in LDS) against the grouped-GEMM path on the same
+    minibatches, incl. a ragged batch and odd widths: same losses (rtol 1e-6) and parameters (2e-6) after 3 steps."""
+    from porl_amd import engine as E
+    kw = {} if hidden is None else {"hidden_layers": hidden}
+    st, ac, rw, ns, dn = make_discrete_transitions(3 * B, S, A, seed=21)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    results = []
+    for fused in (1, 0):
+        try:
+            E.tune_set("qnet_fused", fused)
+            t = _trainer(S, A, B, 4, **kw)
+            assert t._engine.fused == bool(fused)
+            losses = []
+            for k in range(3):
+                sl = slice(k * B, (k + 1) * B)
+                losses.append(t.learn_on(dev(st[sl]), dev(ac[sl]), dev(rw[sl]), dev(ns[sl]), dev(dn[sl])))
+            results.append((losses, _np_sd(t.q_network)))
+        finally:
+            E.tune_set("qnet_fused", 1)
+    np.testing.assert_allclose(results[0][0], results[1][0], rtol=2e-6)
+    for k, v in results[1][1].items():
+        np.testing.assert_allclose(results[0][1][k], v, atol=2e-6, err_msg=k)
+
+
+def test_learn_device_sampled_gathers_inside_the_step_kernel():
+    """`learn_device_sampled` (indices drawn on the device, rows gathered by the step kernel itself) equals
+    `learn_on` applied to the gathered minibatch, bit for bit."""
+    from porl_amd import engine as E
+    S, A, B, N = 60, 10, 512, 5000
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=3)
+    ta, tb = _trainer(S, A, B, 7), _trainer(S, A, B, 7)
+    for t in (ta, tb):
+        rb = t.replay_buffer
+        rb.states[:N], rb.actions[:N], rb.rewards[:N], rb.next_states[:N], rb.dones[:N] = st, ac, rw, ns, dn
+        rb.size, rb.position = N, 0
+    for k in range(3):
+        la = ta.learn_device_sampled(seed=5)
+        tb.replay_buffer._sync_mirror()
+        idx = E.sample_indices(N, B, 5, k, device=DEV)
+        lb = tb.learn_on(*tb.replay_buffer.gather_device(idx))
+        assert la == lb
+    for (k, a), (_, b) in zip(ta.q_network.state_dict().items(), tb.q_network.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("S,A,B,hidden", [(17, 3, 33, (32, 96)), (64, 32, 96, (128, 128, 64)), (5, 2, 1, (7,))])
+def test_one_launch_gradients_on_odd_shapes(S, A, B, hidden):
+    """Engine level: gradients and loss statistics of the one-launch kernel against the grouped-GEMM path for
+    widths that are not multiples of 32, the widest supported network, and a single-row batch."""
+    from porl_amd import engine as E
+    from porl_amd.train.cql_trainer import QnetEngine
+    rng = np.random.default_rng(S * 1000 + A)
+    eng = QnetEngine(S, A, hidden, max(B, 64), DEV)
+    assert eng.fused
+    eng.params.copy_(torch.from_numpy(rng.uniform(-0.3, 0.3, eng.n_params).astype(np.float32)))
+    eng.params_tgt.copy_(torch.from_numpy(rng.uniform(-0.3, 0.3, eng.n_params).astype(np.float32)))
+    st, ac, rw, ns, dn = make_discrete_transitions(B, S, A, seed=8)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    hp = eng.hyper(0.99, 0.7, 1.0 / B, 1, 5e-4)
+    out = []
+    for fused in (1, 0):
+        try:
+            E.tune_set("qnet_fused", fused)
+            eng.load_batch(dev(st), dev(ac), dev(rw), dev(ns), dev(dn))
+            eng.grads.zero_()
+            eng.cql_backward(hp)
+            out.append((eng.grads.cpu().numpy().copy(), eng.stats[:3].cpu().numpy().copy()))
+        finally:
+            E.tune_set("qnet_fused", 1)
+    scale = np.abs(out[1][0]).max()
+    assert np.abs(out[0][0] - out[1][0]).max() <= 2e-6 * max(scale, 1.0)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-6)
+
+
+def test_wide_networks_keep_the_multi_launch_path():
+    from porl_amd.train.cql_trainer import QnetEngine
+    assert not QnetEngine(60, 10, (64, 256, 64), 64, DEV).fused
