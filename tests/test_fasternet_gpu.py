@@ -179,3 +179,34 @@ def test_sorl_update_with_encoder_backbone_matches_reference_golden():
     assert worst < 2e-5, worst                                               # lr 1e-4, 3 Adam steps
     act = agent.select_action(torch.from_numpy(z["s0"].copy()).to(DEV))
     assert act.shape == (B, A) and np.isfinite(act).all()
+
+
+@pytest.mark.parametrize("embed,depths,n_div,mlp_ratio,B", [(64, (2, 1), 4, 2.0, 2), (32, (1, 1), 2, 3.0, 1)])
+def test_other_encoder_shapes_against_oracle(embed, depths, n_div, mlp_ratio, B):
+    """Shapes the reference script does not build (other widths / depths / n_div, a one-sample batch): the
+    patch-matrix fallback of the partial conv and the general block loop, train mode with a dropped sample."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import fasternet_oracle as FO
+    from porl_amd.agent.fasternet import FasterNet
+    torch.manual_seed(11)
+    m = FasterNet(3, 40, embed_dim=embed, depths=depths, n_div=n_div, mlp_ratio=mlp_ratio, feature_dim=96, max_batch=4).to(DEV)
+    sd = {k: v.cpu().numpy().copy() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(embed)
+    st = np.empty((B, 362), dtype=np.float32)
+    st[:, :360] = rng.uniform(0.2, 3.9, size=(B, 360))
+    st[:, 360:] = rng.uniform(-3, 3, size=(B, 2))
+    nb = sum(depths)
+    scale = np.ones((nb, B), dtype=np.float32)
+    scale[-1, 0] = 0.0
+    stats = {k: v.copy() for k, v in sd.items() if "running" in k}
+    ref = FO.forward(sd, stats, st.copy(), True, scale, depths=depths, n_div=n_div)
+    m.train()
+    got = m(torch.from_numpy(st.copy()).to(DEV), drop_scale=torch.from_numpy(scale))
+    if np.abs(ref).max() > 1e-8:
+        assert rel_err(got.cpu().numpy(), ref) < REL
+    else:   # one sample: the last BatchNorm centres every channel over the positions, so the pooled features vanish
+        assert np.abs(got.cpu().numpy()).max() < 1e-8
+    m.eval()
+    ref_eval = FO.forward(sd, stats, st.copy(), False, depths=depths, n_div=n_div)
+    got_eval = m(torch.from_numpy(st.copy()).to(DEV))
+    assert rel_err(got_eval.cpu().numpy(), ref_eval) < REL
