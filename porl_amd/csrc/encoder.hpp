@@ -59,6 +59,162 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------
+// PatchEmbed straight from the lidar state: the costmap image (util/costmap.py:7-64) has at most one beam pixel per
+// row in channel 0 plus a 5-pixel goal cross in all three channels, so 94 % of the 4x4 patches are empty and
+// their convolution is exactly 0.  Instead of rasterising 1.1 MB per sample and convolving it densely, a block
+// marks the set pixels of one patch row as 48-bit masks (bit k = (c, ky, kx), the weight's own order), and a
+// patch's output is the sum of the weight columns of its set bits in ascending k — bit-identical to the dense
+// fmaf chain over {0, 1} pixels.
+//   patch_stats_kernel : BatchNorm batch statistics from the non-empty patches only (fp64, one partial per block)
+//   patch_bn_kernel    : x1 = fma(conv, alpha, beta) for every position (empty patches get beta), NHWC
+// Pixel semantics are costmap_kernel's (kernels.hpp): values > 8 read as 0, beams rolled by n_ang/2, distance bin
+// 0 cleared, python-style wrap of the cross at bin -1.
+// ---------------------------------------------------------------------------------------------------
+struct CostmapGeom { int n_ang, n_dist; float dist_inc, ang_inc, deg_min, deg_max, dist_max; };
+
+// marks the set pixels of patch row py of sample `st` in mask[Wp] (LDS, zeroed by the caller); threads 0..3 take
+// the four beams of the strip, thread 4 the goal cross
+__device__ __forceinline__ void patch_row_masks(const float* __restrict__ st, const CostmapGeom& g, int py,
+                                                unsigned long long* mask, int t) {
+  auto rd = [&](int i) { const float v = st[i]; return v > 8.f ? 0.f : v; };
+  auto wrap = [](long i, int n) { return i < 0 ? i + n : i; };
+  auto set = [&](int c, int ky, long col) {
+    atomicOr(&mask[col >> 2], 1ull << (c * 16 + ky * 4 + (int)(col & 3)));
+  };
+  if (t < 4) {
+    const int r = 4 * py + t;
+    const int src = (r - g.n_ang / 2 + g.n_ang) % g.n_ang;
+    const long bin = (long)(rd(src) / g.dist_inc);
+    if (bin > 0 && bin < g.n_dist) set(0, t, bin);
+  } else if (t == 4) {
+    const float gx = rd(g.n_ang), gy = rd(g.n_ang + 1);
+    float deg = atan2f(gy, gx);
+    deg = fminf(fmaxf(deg, g.deg_min), g.deg_max);
+    const long deg_bin = (long)((deg + 3.14159265358979323846f) / g.ang_inc);
+    const float cd = fminf(sqrtf(gx * gx + gy * gy), g.dist_max);
+    const long dist_bin = (long)(cd / g.dist_inc);
+    for (int ky = 0; ky < 4; ++ky) {
+      const long r = 4 * py + ky;
+      const bool is_deg = r == wrap(deg_bin, g.n_ang);
+      const bool near = is_deg || r == wrap(deg_bin - 1, g.n_ang) || r == wrap(deg_bin + 1, g.n_ang);
+      for (int c = 0; c < 3; ++c) {
+        if (near) set(c, ky, wrap(dist_bin, g.n_dist));
+        if (is_deg) { set(c, ky, wrap(dist_bin - 1, g.n_dist)); set(c, ky, wrap(dist_bin + 1, g.n_dist)); }
+      }
+    }
+  }
+}
+
+// sum of the weight columns of the set bits, ascending k; wl = [48][E] in LDS
+__device__ __forceinline__ float patch_value(unsigned long long m, const float* wl, int E, int e) {
+  float acc = 0.f;
+  while (m) {
+    const int k = __builtin_ctzll(m);
+    acc = acc + wl[k * E + e];
+    m &= m - 1;
+  }
+  return acc;
+}
+
+constexpr int PE_MAX_E = 128;
+
+// One block per sample (grid-stride): all Hp*Wp masks of the sample at once, the non-empty patches compacted into
+// a list, then thread (e, half) adds the values of channel e over its half of the list in list order (fp64).
+__global__ __launch_bounds__(256) void patch_stats_kernel(const float* __restrict__ state, long state_rs, int batch,
+                                                          CostmapGeom g, const float* __restrict__ w, int E,
+                                                          double* __restrict__ partial) {
+  extern __shared__ float ps_lds[];
+  const int Wp = g.n_dist >> 2, Hp = g.n_ang >> 2, P = Hp * Wp;
+  float* wl = ps_lds;                                                                     // [48][E]
+  unsigned long long* mask = reinterpret_cast<unsigned long long*>(ps_lds + PE_K * E);   // [P]
+  int* list = reinterpret_cast<int*>(mask + P);                                          // [P] (worst case)
+  __shared__ int n_list;
+  __shared__ int counts[256];
+  __shared__ double red[2][2 * PE_MAX_E];
+  const int t = threadIdx.x;
+  for (int i = t; i < PE_K * E; i += 256) {
+    const int e = i / PE_K, k = i - e * PE_K;
+    wl[k * E + e] = w[i];
+  }
+  const int e = t % E, half = t / E;            // threads >= 2E idle in the accumulation (E >= 128: one half only)
+  const int halves = 256 / E >= 2 ? 2 : 1;
+  double s = 0, q = 0;
+  for (int b = blockIdx.x; b < batch; b += gridDim.x) {
+    const float* st = state + (long)b * state_rs;
+    __syncthreads();                                             // list/masks of the previous sample are consumed
+    for (int i = t; i < P; i += 256) mask[i] = 0ull;
+    __syncthreads();
+    for (int py = t >> 3; py < Hp; py += 32) patch_row_masks(st, g, py, mask + py * Wp, t & 7);
+    __syncthreads();
+    // ordered compaction (thread t owns a contiguous chunk of patches): the list, and with it the order of the
+    // fp64 sums, is the same on every run
+    {
+      const int chunk = (P + 255) / 256, i0 = t * chunk, i1 = min(P, i0 + chunk);
+      int cnt = 0;
+      for (int i = i0; i < i1; ++i) cnt += mask[i] != 0ull;
+      counts[t] = cnt;
+      __syncthreads();
+      int off = 0;
+      for (int j = 0; j < t; ++j) off += counts[j];
+      for (int i = i0; i < i1; ++i)
+        if (mask[i]) list[off++] = i;
+      if (t == 255) n_list = off;
+    }
+    __syncthreads();
+    if (half < halves) {
+      const int n = n_list;
+      for (int i = half; i < n; i += halves) {
+        const float v = patch_value(mask[list[i]], wl, E, e);
+        s += v;
+        q += (double)v * v;
+      }
+    }
+  }
+  if (half < halves) { red[half][e] = s; red[half][E + e] = q; }
+  __syncthreads();
+  if (t < 2 * E) {
+    double r = red[0][t];
+    if (halves == 2) r += red[1][t];
+    partial[(long)blockIdx.x * 2 * E + t] = r;
+  }
+}
+
+// thread i of a block = (patch column i / (E/4), channel group i % (E/4)): consecutive lanes write consecutive
+// 16-byte pieces of the output rows
+__global__ __launch_bounds__(256) void patch_bn_kernel(const float* __restrict__ state, long state_rs, CostmapGeom g,
+                                                       const float* __restrict__ w, int E, const float* __restrict__ alpha,
+                                                       const float* __restrict__ beta, float* __restrict__ out) {
+  extern __shared__ float ps_lds[];
+  float* wl = ps_lds;
+  unsigned long long* mask = reinterpret_cast<unsigned long long*>(ps_lds + PE_K * E);
+  const int t = threadIdx.x, e4n = E >> 2, Wp = g.n_dist >> 2, Hp = g.n_ang >> 2;
+  const int py = blockIdx.x;
+  const long b = blockIdx.y;
+  for (int i = t; i < PE_K * E; i += 256) {
+    const int e = i / PE_K, k = i - e * PE_K;
+    wl[k * E + e] = w[i];
+  }
+  for (int i = t; i < Wp; i += 256) mask[i] = 0ull;
+  __syncthreads();
+  patch_row_masks(state + b * state_rs, g, py, mask, t);
+  __syncthreads();
+  float* orow = out + (b * Hp + py) * (long)Wp * E;
+  for (int i = t; i < Wp * e4n; i += 256) {
+    const int px = i / e4n, c = (i - px * e4n) << 2;
+    const unsigned long long m = mask[px];
+    const float4 a4 = *reinterpret_cast<const float4*>(alpha + c);
+    float4 o = *reinterpret_cast<const float4*>(beta + c);      // fma(0, alpha, beta)
+    if (m) {
+      o.x = fmaf(patch_value(m, wl, E, c), a4.x, o.x);
+      o.y = fmaf(patch_value(m, wl, E, c + 1), a4.y, o.y);
+      o.z = fmaf(patch_value(m, wl, E, c + 2), a4.z, o.z);
+      o.w = fmaf(patch_value(m, wl, E, c + 3), a4.w, o.w);
+    }
+    reinterpret_cast<float4*>(orow)[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // BatchNorm2d batch statistics (fasternet.py:164,240,255 in train mode): per-channel sum and sum of squares
 // of an (M, C) row-major activation, accumulated in fp64 like the CPU reference's accumulate type.
 // Stage 1: each block owns a contiguous row range and writes one partial per channel; stage 2 (one

@@ -210,3 +210,27 @@ def test_other_encoder_shapes_against_oracle(embed, depths, n_div, mlp_ratio, B)
     ref_eval = FO.forward(sd, stats, st.copy(), False, depths=depths, n_div=n_div)
     got_eval = m(torch.from_numpy(st.copy()).to(DEV))
     assert rel_err(got_eval.cpu().numpy(), ref_eval) < REL
+
+
+def test_sparse_patch_embedding_equals_the_dense_one():
+    """PatchEmbed + BatchNorm computed from the lidar state through per-patch pixel masks (no costmap image) against
+    rasterise + dense 4x4 convolution + column statistics: same sums in the same order, so features agree to the
+    last bits of the BatchNorm statistics (1e-6 relative), incl. goal-cross edge cases and > 8 clamping."""
+    from porl_amd import engine as E
+    z, _ = load_golden("costmap_b24")
+    st = z["state_in"].copy()
+    outs = []
+    for dense in (0, 1):
+        try:
+            E.tune_set("enc_dense_patch", dense)
+            m = build(2, max_batch=24)
+            m.train()
+            x = torch.from_numpy(st.copy()).to(DEV)
+            f = m(x, drop_scale=torch.ones(3, 24))
+            outs.append((f.cpu().numpy(), x.cpu().numpy(), {k: v.cpu().numpy() for k, v in m.state_dict().items() if "running" in k}))
+        finally:
+            E.tune_set("enc_dense_patch", 0)
+    assert rel_err(outs[0][0], outs[1][0].astype(np.float64)) < 1e-6
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][1], z["state_after"])
+    for k in outs[0][2]:
+        np.testing.assert_allclose(outs[0][2][k], outs[1][2][k], rtol=1e-6, atol=1e-12)
