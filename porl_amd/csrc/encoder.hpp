@@ -436,18 +436,6 @@ __global__ void pack_pconv_kernel(const float* __restrict__ src, float* __restri
   }
 }
 
-// x[m, :] += scale[sample(m)] * z[m, :]   (MLPBlock.forward, fasternet.py:186-190; scale is the DropPath
-// keep mask already divided by keep_prob, :86-93; NULL = 1).  Product and sum rounded separately, as
-// eager PyTorch does.
-__global__ __launch_bounds__(256) void residual_kernel(float* __restrict__ x, const float* __restrict__ z, long n4,
-                                                       long per_sample4, const float* __restrict__ scale) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const float s = scale ? scale[i / per_sample4] : 1.f;
-    const float4 a = reinterpret_cast<const float4*>(x)[i], b = reinterpret_cast<const float4*>(z)[i];
-    reinterpret_cast<float4*>(x)[i] = make_float4(__fadd_rn(a.x, __fmul_rn(b.x, s)), __fadd_rn(a.y, __fmul_rn(b.y, s)),
-                                                  __fadd_rn(a.z, __fmul_rn(b.z, s)), __fadd_rn(a.w, __fmul_rn(b.w, s)));
-  }
-}
 
 // PatchMerging.reduction input (fasternet.py:253, Conv2d(C, 2C, 2, stride 2)): (B, H, W, C) -> (B*H/2*W/2, 4C)
 // with k = (ky, kx, c)

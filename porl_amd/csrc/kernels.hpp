@@ -97,66 +97,6 @@ __global__ __launch_bounds__(1024) void value_loss_kernel(const ValueLossArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// scalar-head weight gradient: dW[j] = sum_b dv[b] * H[b, j];  db = sum_b dv[b]
-// grid (ceil(H/64), nets), block 256 = 16 column-quads x 16 row lanes
-// ---------------------------------------------------------------------------------------------------
-struct HeadWgradArgs {
-  const float* H[2]; const float* dv[2]; float* dW[2]; float* db[2];
-  int B, Hdim, ld, nnets;
-};
-
-__global__ __launch_bounds__(256) void head_wgrad_kernel(const HeadWgradArgs a) {
-  __shared__ float4 red[256];
-  const int net = blockIdx.y;
-  const float* __restrict__ Hm = a.H[net];
-  const float* __restrict__ dv = a.dv[net];
-  const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int col = blockIdx.x * 64 + c4 * 4;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  float sb = 0.f;
-  const bool vec = (a.ld & 3) == 0 && col + 3 < a.Hdim;
-  for (int b = rl; b < a.B; b += 16) {
-    const float d = dv[b];
-    sb += d;
-    const float* p = Hm + (size_t)b * a.ld + col;
-    if (vec) {
-      const float4 h = *reinterpret_cast<const float4*>(p);
-      s.x += d * h.x; s.y += d * h.y; s.z += d * h.z; s.w += d * h.w;
-    } else {
-      if (col < a.Hdim) s.x += d * p[0];
-      if (col + 1 < a.Hdim) s.y += d * p[1];
-      if (col + 2 < a.Hdim) s.z += d * p[2];
-      if (col + 3 < a.Hdim) s.w += d * p[3];
-    }
-  }
-  red[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x < 16) {
-    float4 t = red[threadIdx.x];
-    for (int r = 1; r < 16; ++r) {
-      const float4 o = red[r * 16 + threadIdx.x];
-      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
-    }
-    float* out = a.dW[net];
-    if (col < a.Hdim) out[col] = t.x;
-    if (col + 1 < a.Hdim) out[col + 1] = t.y;
-    if (col + 2 < a.Hdim) out[col + 2] = t.z;
-    if (col + 3 < a.Hdim) out[col + 3] = t.w;
-  }
-  if (blockIdx.x == 0) {   // bias gradient: threads with c4 == 0 hold disjoint row subsets
-    __syncthreads();
-    float* rf = reinterpret_cast<float*>(red);
-    if (c4 == 0) rf[rl] = sb;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float t = 0.f;
-      for (int r = 0; r < 16; ++r) t += rf[r];
-      a.db[net][0] = t;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // advantage weight + diagonal-Gaussian NLL + its gradient   (agent/por.py:97-106, policy.py:18-23)
 //   one wave per row, lane j handles columns j, j+64, ...
 // ---------------------------------------------------------------------------------------------------
@@ -271,35 +211,6 @@ __global__ __launch_bounds__(256) void policy_nll_kernel(const PolicyNllArgs a) 
   }
 }
 
-// stats[1] = g_loss, stats[2] = min nlp, grad(log_std).  One wave per log_std column (lanes stride over
-// the per-block partials, then a fixed-order wave reduction); the last block reduces loss and min.
-// grid = ceil(D / 4) + 1, block = 256
-__global__ __launch_bounds__(256) void policy_nll_finalize_kernel(const float* __restrict__ part_loss,
-                                                                   const float* __restrict__ part_min,
-                                                                   const float* __restrict__ part_dls, int nblk, int D,
-                                                                   const float* __restrict__ log_std,
-                                                                   float* __restrict__ g_log_std,
-                                                                   float* __restrict__ stats) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (blockIdx.x + 1 == gridDim.x) {
-    if (wave == 0) {
-      float s = 0.f, m = INFINITY;
-      for (int k = lane; k < nblk; k += 64) { s += part_loss[k]; m = fminf(m, part_min[k]); }
-      s = wave_sum(s); m = wave_min(m);
-      if (lane == 0) { stats[1] = s; stats[2] = m; }
-    }
-    return;
-  }
-  const int j = blockIdx.x * 4 + wave;
-  if (j >= D) return;
-  float s = 0.f;
-  for (int k = lane; k < nblk; k += 64) s += part_dls[(size_t)k * D + j];
-  s = wave_sum(s);
-  if (lane == 0) {
-    const float ls = log_std[j];
-    g_log_std[j] = (ls >= LOG_STD_MIN && ls <= LOG_STD_MAX) ? s : 0.f;   // clamp passes no gradient outside
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // torch.optim.Adam (single-tensor arithmetic) over a flat parameter group, with the
