@@ -246,6 +246,11 @@ int porl_gather_rows(const float* rows, int64_t row_stride, const int64_t* idx, 
  * replace=False), buffer/replay_buffer.py:64; the stream differs from numpy's). */
 int porl_sample_indices(int64_t n_rows, int32_t batch, uint64_t seed, uint64_t step, int64_t base,
                         int64_t* out, void* stream);
+/* Positions first .. first+count-1 of the keyed permutation (seed, epoch) of [0, n_rows): consecutive calls walk
+ * one shuffled epoch — DataLoader(shuffle=True, drop_last=False) of por_train.py:61-63 without host work; the
+ * last call of an epoch simply asks for fewer rows.  out[i] = base + perm(first + i), int64. */
+int porl_epoch_indices(int64_t n_rows, int64_t first, int32_t count, uint64_t seed, uint64_t epoch, int64_t base,
+                       int64_t* out, void* stream);
 
 /* state2costmap (util/costmap.py:7-64; called by FasterNet.forward_cls, agent/fasternet.py:431):
  * (batch, n_ang + 2) lidar ranges + relative goal (x, y), row stride state_rs -> out (batch, 3, n_ang, n_dist)

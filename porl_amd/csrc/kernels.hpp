@@ -403,11 +403,12 @@ __global__ __launch_bounds__(256) void sampled_batch_kernel(const SampledBatchAr
   }
 }
 
+// out[i] = base + perm_{seed,step}(first + i): `batch` consecutive positions of one keyed permutation of [0, n)
 __global__ void sample_indices_kernel(int64_t n, int batch, uint64_t seed, uint64_t step, int hb,
-                                      int64_t base, int64_t* __restrict__ out) {
+                                      int64_t base, int64_t first, int64_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= batch) return;
-  out[i] = base + feistel_index(n, i, seed, step, hb);
+  out[i] = base + feistel_index(n, first + i, seed, step, hb);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -940,7 +940,19 @@ int porl_sample_indices(int64_t n_rows, int32_t batch, uint64_t seed, uint64_t s
   if (n_rows > (int64_t(1) << 40)) PORL_FAIL(PORL_ERR_INVALID, "n_rows too large");
   const int hb = feistel_half_bits(n_rows);
   hipLaunchKernelGGL(sample_indices_kernel, dim3(cdiv(batch, 256)), dim3(256), 0, (hipStream_t)stream, n_rows, batch,
-                     seed, step, hb, base, out);
+                     seed, step, hb, base, (int64_t)0, out);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_epoch_indices(int64_t n_rows, int64_t first, int32_t count, uint64_t seed, uint64_t epoch, int64_t base,
+                       int64_t* out, void* stream) {
+  if (n_rows < 1 || count < 1 || first < 0 || first + count > n_rows || !out)
+    PORL_FAIL(PORL_ERR_INVALID, "need 0 <= first, 1 <= count, first + count <= n_rows");
+  if (n_rows > (int64_t(1) << 40)) PORL_FAIL(PORL_ERR_INVALID, "n_rows too large");
+  const int hb = feistel_half_bits(n_rows);
+  hipLaunchKernelGGL(sample_indices_kernel, dim3(cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, n_rows, count,
+                     seed, epoch, hb, base, first, out);
   PORL_HIP(hipGetLastError());
   return PORL_OK;
 }

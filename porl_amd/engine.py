@@ -229,6 +229,15 @@ def sample_indices(n_rows, batch, seed, step, out=None, base=0, device="cuda"):
     return out
 
 
+def epoch_indices(n_rows, first, count, seed, epoch, out=None, base=0, device="cuda"):
+    """Positions first..first+count-1 of the keyed permutation (seed, epoch) of [0, n_rows) (int64, on the device)."""
+    if out is None:
+        out = torch.empty(count, dtype=torch.int64, device=device)
+    N.check(N.lib().porl_epoch_indices(n_rows, first, count, seed, epoch, base, N.ptr(out), N.current_stream_ptr()),
+            "porl_epoch_indices")
+    return out
+
+
 def prof_enable(on=True):
     N.check(N.lib().porl_prof_enable(int(on)), "porl_prof_enable")
 

@@ -164,3 +164,18 @@ def test_dp_gradient_sum_equals_global_batch(tmp_path):
     np.testing.assert_allclose(got["flat"], ref, atol=1e-7, rtol=1e-5)
     np.testing.assert_allclose(got["stats"][0], v_loss, rtol=1e-6)
     assert got["stats"][2] == 0.0                       # MIN over ranks
+
+
+def test_pack_csv_dir_concatenates_the_reference_shard_format(tmp_path):
+    """dataloader/dataloader.py:19-20 reads `np.loadtxt(f, delimiter=',').reshape(-1, row_width)` per shard."""
+    import numpy as np
+    from porl_amd.dataloader import pack_csv_dir
+    rng = np.random.default_rng(0)
+    width = 12
+    shards = [rng.normal(size=(n, width)).astype(np.float32) for n in (100, 100, 37)]
+    for i, s in enumerate(shards):
+        np.savetxt(tmp_path / f"dataset_{i}.csv", s.reshape(1, -1) if i == 2 else s, delimiter=",", fmt="%.9g")
+    out = pack_csv_dir(str(tmp_path), str(tmp_path / "packed.npy"), width)
+    rows = np.load(out, mmap_mode="r")
+    assert rows.dtype == np.float32 and rows.shape == (237, width)
+    assert np.array_equal(np.asarray(rows), np.concatenate(shards))
