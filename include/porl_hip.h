@@ -303,6 +303,19 @@ int porl_enc_bind(porl_enc* h, float* params, float* bn_stats, float* workspace)
 int porl_enc_forward(porl_enc* h, float* state, int64_t state_rs, int32_t batch, int32_t training,
                      const float* drop_scale, float* features, int64_t feat_rs, void* stream);
 
+/* Prioritized replay on the device (src/porl/buffer/sum_tree.py:4-77, prioritized_replay_buffer.py:36-108).
+ * `tree`: 2*capacity-1 doubles in the reference's heap layout (leaf of data slot d at d + capacity - 1).
+ * porl_per_update: SumTree.update for a batch (add() and update_priorities()): leaf <- (|td_error| + eps)^alpha,
+ *   a leaf named twice keeps the last value, ancestors are recomputed from their children.  `stamp`: capacity
+ *   zero-initialised int32 of scratch that the call leaves zeroed.
+ * porl_per_sample: PrioritizedReplayBuffer.sample: segment i of the total priority, s = a + (b-a)*u[i] with the
+ *   caller's uniforms u (random.random() of the reference's generator), tree walk -> out_idx (tree indices);
+ *   out_prio needs 2*batch doubles (priorities, then scratch); out_w = (n_entries * p/total)^-beta / max. */
+int porl_per_update(double* tree, int64_t capacity, const int64_t* tree_idx, const double* td_error, int32_t n,
+                    double eps, double alpha, int32_t* stamp, void* stream);
+int porl_per_sample(const double* tree, int64_t capacity, const double* u, int32_t batch, int64_t n_entries,
+                    double beta, int64_t* out_idx, double* out_prio, float* out_w, void* stream);
+
 /* Experiment knobs (scheduling only, never the mathematics).  "gemm_lds_pad": extra dynamic LDS bytes per GEMM
  * block, limiting how many blocks share a CU.  "qnet_fused": 0 forces the multi-launch CQL path. */
 int porl_tune_set(const char* key, int value);

@@ -17,6 +17,8 @@ What is pinned:
   fasternet_*: FasterNet(3, 256).forward_cls (/root/reference/agent/fasternet.py:428-438) in eval mode and in
             train mode (batch-stat BatchNorm, running-stat update, DropPath masks replayed from the seed)
   sorl_enc_*: SORL.update with the FasterNet backbone (/root/reference/agent/sorl.py:78-128)
+  per_*   : PrioritizedReplayBuffer.add/sample/update_priorities under random.seed
+            (/root/reference/src/porl/buffer/prioritized_replay_buffer.py:36-108, sum_tree.py:4-77)
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py </dev/null
 """
@@ -405,6 +407,40 @@ def gen_sorl_enc(name, B=6, K=3, H=64, L=2, A=2, F=256, seed_model=0, seed_data=
     print(f"{name}: losses={losses}")
 
 
+def gen_per(name, cap=300, N=450, S=6, B=64, seed=17):
+    """PrioritizedReplayBuffer (src/porl/buffer/prioritized_replay_buffer.py:7-108): ring of `cap` filled with N > cap
+    adds, two samples under random.seed, a priority write-back with a duplicated index, a third sample."""
+    import random
+    from porl.buffer.prioritized_replay_buffer import PrioritizedReplayBuffer
+    rng = np.random.default_rng(seed)
+    buf = PrioritizedReplayBuffer(cap, alpha=0.6, beta_start=0.4, beta_frames=1000)
+    st = rng.normal(size=(N, S)).astype(np.float32)
+    ns = rng.normal(size=(N, S)).astype(np.float32)
+    ac = rng.integers(0, 4, size=N)
+    rw = rng.normal(size=N).astype(np.float32)
+    dn = (rng.uniform(size=N) < 0.1).astype(np.float32)
+    td = np.abs(rng.normal(size=N)) + 0.01
+    for i in range(N):
+        buf.add(td[i], st[i], int(ac[i]), float(rw[i]), ns[i], float(dn[i]))
+    out = dict(meta=np.array([cap, N, S, B, seed]), st=st, ns=ns, ac=ac, rw=rw, dn=dn, td=td)
+    random.seed(seed)
+    for k in range(2):
+        s, a, r, n2, d, w, idxs = buf.sample(B)
+        out[f"idx{k}"], out[f"w{k}"], out[f"s{k}"], out[f"a{k}"], out[f"r{k}"] = np.array(idxs), w, s, a, r
+    new_td = np.abs(rng.normal(size=B))
+    upd_idx = np.array(out["idx1"])
+    upd_idx[5] = upd_idx[3]                                   # the same leaf twice: the later value must win
+    buf.update_priorities(list(upd_idx), new_td)
+    out["upd_idx"], out["upd_td"] = upd_idx, new_td
+    s, a, r, n2, d, w, idxs = buf.sample(B)
+    out["idx2"], out["w2"], out["s2"] = np.array(idxs), w, s
+    out["tree_after"] = buf.tree.tree.copy()
+    out["total"] = np.float64(buf.tree.total_priority())
+    out["beta"] = np.float64(buf.beta)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: total={out['total']:.6f} beta={out['beta']:.4f}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -432,6 +468,8 @@ def main():
     # FasterNet costmap encoder (config 5) and SORL with it as backbone
     gen_fasternet("fasternet_b5", B=5)
     gen_sorl_enc("sorl_enc_b6", B=6, K=3)
+    # prioritized replay (next row)
+    gen_per("per_cap300")
 
 
 if __name__ == "__main__":

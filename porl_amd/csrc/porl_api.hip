@@ -14,6 +14,7 @@
 #include "gemm_f32.hpp"
 #include "kernels.hpp"
 #include "qnet_fused.hpp"
+#include "per_tree.hpp"
 
 using namespace porl;
 
@@ -953,6 +954,32 @@ int porl_epoch_indices(int64_t n_rows, int64_t first, int32_t count, uint64_t se
   const int hb = feistel_half_bits(n_rows);
   hipLaunchKernelGGL(sample_indices_kernel, dim3(cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, n_rows, count,
                      seed, epoch, hb, base, first, out);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+// ---- prioritized replay: sum tree in HBM (per_tree.hpp) ------------------------------------------------------
+int porl_per_update(double* tree, int64_t capacity, const int64_t* tree_idx, const double* td_error, int32_t n, double eps,
+                    double alpha, int32_t* stamp, void* stream) {
+  if (!tree || !tree_idx || !td_error || !stamp || capacity < 1 || n < 0) PORL_FAIL(PORL_ERR_INVALID, "bad arguments");
+  if (n == 0) return PORL_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(per_stamp_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, tree_idx, n, capacity, stamp);
+  hipLaunchKernelGGL(per_set_leaves_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, tree, tree_idx, td_error, n, capacity, eps,
+                     alpha, stamp);
+  int levels = 0;
+  for (int64_t v = 2 * capacity - 1; v > 1; v >>= 1) ++levels;          // depth of the deepest leaf
+  hipLaunchKernelGGL(per_propagate_kernel, dim3(1), dim3(1024), 0, s, tree, tree_idx, n, levels);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_per_sample(const double* tree, int64_t capacity, const double* u, int32_t batch, int64_t n_entries, double beta,
+                    int64_t* out_idx, double* out_prio, float* out_w, void* stream) {
+  if (!tree || !u || !out_idx || !out_prio || !out_w || capacity < 1 || batch < 1 || n_entries < 1)
+    PORL_FAIL(PORL_ERR_INVALID, "bad arguments");
+  PerSampleArgs a{tree, capacity, u, batch, n_entries, beta, out_idx, out_prio, out_w};
+  hipLaunchKernelGGL(per_sample_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   PORL_HIP(hipGetLastError());
   return PORL_OK;
 }

@@ -1,0 +1,73 @@
+"""Prioritized replay with the sum tree on the device against the reference's golden run
+(tests/golden/per_cap300.npz from /root/reference/src/porl/buffer/prioritized_replay_buffer.py via
+oracle/gen_golden.py): same tree indices under the same `random` stream, same importance weights, same tree."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+def _filled(z):
+    from porl_amd.buffer.prioritized_replay_buffer import PrioritizedReplayBuffer
+    cap, N, S, B, seed = (int(v) for v in z["meta"])
+    buf = PrioritizedReplayBuffer(cap, alpha=0.6, beta_start=0.4, beta_frames=1000, device=DEV)
+    for i in range(N):
+        buf.add(z["td"][i], z["st"][i], int(z["ac"][i]), float(z["rw"][i]), z["ns"][i], float(z["dn"][i]))
+    return buf, cap, N, S, B, seed
+
+
+def test_sampling_weights_and_write_back_match_the_reference():
+    z, _ = load_golden("per_cap300")
+    buf, cap, N, S, B, seed = _filled(z)
+    assert len(buf) == cap
+    random.seed(seed)
+    for k in range(2):
+        s, a, r, n2, d, w, idxs = buf.sample(B)
+        assert np.array_equal(idxs.cpu().numpy(), z[f"idx{k}"])
+        np.testing.assert_allclose(w.cpu().numpy(), z[f"w{k}"], rtol=2e-7)
+        assert np.array_equal(s.cpu().numpy(), z[f"s{k}"]) and np.array_equal(a.cpu().numpy(), z[f"a{k}"])
+        assert np.array_equal(r.cpu().numpy(), z[f"r{k}"])
+    buf.update_priorities(list(z["upd_idx"]), z["upd_td"])          # contains one leaf twice: the later value wins
+    s, a, r, n2, d, w, idxs = buf.sample(B)
+    assert np.array_equal(idxs.cpu().numpy(), z["idx2"])
+    np.testing.assert_allclose(w.cpu().numpy(), z["w2"], rtol=2e-7)
+    assert np.array_equal(s.cpu().numpy(), z["s2"])
+    np.testing.assert_allclose(buf.tree.cpu().numpy(), z["tree_after"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(buf.total_priority(), float(z["total"]), rtol=1e-13)
+    assert abs(float(buf.beta) - float(z["beta"])) < 1e-15
+
+
+def test_tree_invariants_at_scale():
+    """capacity 100 000 (the reference trainer's size): every internal node equals the sum of its children bit for
+    bit, sampled leaves carry positive priority, and frequencies follow the priorities."""
+    from porl_amd.buffer.prioritized_replay_buffer import PrioritizedReplayBuffer
+    cap, S = 100_000, 4
+    buf = PrioritizedReplayBuffer(cap, device=DEV, state_shape=(S,))
+    rng = np.random.default_rng(0)
+    buf._alloc(np.zeros(S, np.float32))
+    buf.n_entries = cap
+    td = torch.from_numpy(rng.uniform(0.01, 1.0, size=cap)).to(DEV)
+    td[:10] = 50.0                                                    # ten heavy leaves
+    idx = torch.arange(cap, device=DEV) + (cap - 1)
+    for a in range(0, cap, 4096):
+        buf._update(idx[a:a + 4096].contiguous(), td[a:a + 4096].contiguous())
+    t = buf.tree.cpu().numpy()
+    inner = np.arange(cap - 1)
+    assert np.array_equal(t[inner], t[2 * inner + 1] + t[2 * inner + 2])
+    random.seed(1)
+    hits = np.zeros(cap, dtype=np.int64)
+    for _ in range(20):
+        *_, w, idxs = buf.sample(4096)
+        slots = (idxs - (cap - 1)).cpu().numpy()
+        assert slots.min() >= 0 and slots.max() < cap
+        np.add.at(hits, slots, 1)
+        assert float(w.max()) == 1.0 and float(w.min()) > 0
+    p = t[cap - 1:] / t[0]
+    expect_heavy = 20 * 4096 * p[:10].sum()
+    assert abs(hits[:10].sum() - expect_heavy) < 6 * np.sqrt(expect_heavy)
