@@ -210,6 +210,21 @@ int32_t porl_qnet_one_launch(const porl_qnet* h);
 int porl_qnet_learn_indexed(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions,
                             const float* rewards, const float* next_states, int64_t n_rs, const float* dones,
                             const int64_t* idx, int32_t batch, const porl_qnet_hyper* hp, void* stream);
+/* porl_qnet_learn_indexed with the loss of src/porl/train/dqn_per_trainer.py:75-123: Double-DQN target
+ * (argmax by the online net, value by the target net), importance-sampling weights, |TD error| per sample for the
+ * priority write-back.  Use hp->alpha = 0 for plain (un-regularised) DQN.  The reference multiplies a (B,1) weight
+ * tensor with a (B,) error tensor, i.e. its loss is mean(w) * mean(td^2): pass that mean as `uniform_weight`
+ * (device scalar) to reproduce it, or `is_weights` (B,) for per-sample weighting; either may be NULL. */
+typedef struct porl_qnet_variant {
+  int32_t double_dqn;
+  const float* is_weights;
+  const float* uniform_weight;
+  float* td_abs;
+} porl_qnet_variant;
+int porl_qnet_learn_variant(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions,
+                            const float* rewards, const float* next_states, int64_t n_rs, const float* dones,
+                            const int64_t* idx, int32_t batch, const porl_qnet_hyper* hp,
+                            const porl_qnet_variant* variant, void* stream);
 int porl_qnet_sync_target(porl_qnet* h, void* stream);
 /* q_network(states) (which=0) or target_network(states) (which=1) -> (batch, n_actions) */
 int porl_qnet_forward(porl_qnet* h, int which, const float* states, int64_t s_rs, int32_t batch,

@@ -17,7 +17,8 @@ What is pinned:
   fasternet_*: FasterNet(3, 256).forward_cls (/root/reference/agent/fasternet.py:428-438) in eval mode and in
             train mode (batch-stat BatchNorm, running-stat update, DropPath masks replayed from the seed)
   sorl_enc_*: SORL.update with the FasterNet backbone (/root/reference/agent/sorl.py:78-128)
-  per_*   : PrioritizedReplayBuffer.add/sample/update_priorities under random.seed
+  per_*   : PrioritizedReplayBuffer.add/sample/update_priorities under random.seed; per_trainer_*: PERTrainer.learn
+            (/root/reference/src/porl/train/dqn_per_trainer.py:67-123)
             (/root/reference/src/porl/buffer/prioritized_replay_buffer.py:36-108, sum_tree.py:4-77)
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py </dev/null
@@ -441,6 +442,44 @@ def gen_per(name, cap=300, N=450, S=6, B=64, seed=17):
     print(f"{name}: total={out['total']:.6f} beta={out['beta']:.4f}")
 
 
+def gen_per_trainer(name, S=12, A=5, B=64, K=4, N=400, cap=512, seed_model=2, seed_data=23, seed_rand=5, gamma=0.99):
+    """PERTrainer.learn (src/porl/train/dqn_per_trainer.py:67-123) as an unbound method on a hand-built object (the
+    constructor needs gymnasium): Double-DQN target, the (B,1)x(B,) weighted loss as written, Adam, priority
+    write-back, K steps under random.seed."""
+    import random
+    _stub_cql_imports()
+    from porl.train.dqn_per_trainer import PERTrainer
+    from porl.net.q_network import QNetwork
+    from porl.buffer.prioritized_replay_buffer import PrioritizedReplayBuffer
+    dev = torch.device("cpu")
+    torch.manual_seed(seed_model)
+    t = object.__new__(PERTrainer)
+    t.q_network = QNetwork(S, A).to(dev)
+    t.target_network = QNetwork(S, A).to(dev)
+    t.target_network.load_state_dict(t.q_network.state_dict())
+    with torch.no_grad():                                      # a target that differs from the online net
+        for p in t.target_network.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    t.optimizer = torch.optim.Adam(t.q_network.parameters(), lr=0.0005)
+    t.memory = PrioritizedReplayBuffer(cap, alpha=0.6, beta_start=0.4, beta_frames=1000)
+    t.batch_size, t.gamma, t.device = B, gamma, dev
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=seed_data)
+    for i in range(N):
+        t.memory.add(1.0, st[i], int(ac[i]), float(rw[i]), ns[i], float(dn[i]))
+    out = {"meta": np.array([S, A, B, K, N, cap, seed_model, seed_data, seed_rand]), "gamma": np.float64(gamma)}
+    out.update(pack("init/", sd_np(t.q_network)))
+    out.update(pack("init_target/", sd_np(t.target_network)))
+    random.seed(seed_rand)
+    losses = []
+    for k in range(K):
+        losses.append(PERTrainer.learn(t))
+    out["loss"] = np.array(losses, dtype=np.float64)
+    out.update(pack("final/", sd_np(t.q_network)))
+    out["tree_after"] = t.memory.tree.tree.copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={losses}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -470,6 +509,7 @@ def main():
     gen_sorl_enc("sorl_enc_b6", B=6, K=3)
     # prioritized replay (next row)
     gen_per("per_cap300")
+    gen_per_trainer("per_trainer_s12_a5")
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@ SYMBOLS = [
     "porl_qnet_create", "porl_qnet_destroy", "porl_qnet_param_floats", "porl_qnet_tensors",
     "porl_qnet_tensor_info", "porl_qnet_workspace_floats", "porl_qnet_bind", "porl_qnet_load_batch",
     "porl_qnet_cql_backward", "porl_qnet_apply", "porl_qnet_learn", "porl_qnet_sync_target",
-    "porl_qnet_forward", "porl_qnet_penalty", "porl_qnet_learn_indexed", "porl_qnet_one_launch",
+    "porl_qnet_forward", "porl_qnet_penalty", "porl_qnet_learn_indexed", "porl_qnet_one_launch", "porl_qnet_learn_variant",
     "porl_enc_create", "porl_enc_destroy", "porl_enc_param_floats", "porl_enc_stat_floats",
     "porl_enc_workspace_floats", "porl_enc_tensors", "porl_enc_norms", "porl_enc_blocks",
     "porl_enc_tensor_info", "porl_enc_norm_info", "porl_enc_bind", "porl_enc_forward",
@@ -64,6 +64,11 @@ class QnetBuffers(C.Structure):
 class QnetHyper(C.Structure):
     _fields_ = [("gamma", C.c_float), ("alpha", C.c_float), ("inv_batch", C.c_float), ("step", C.c_int32),
                 ("lr", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double)]
+
+
+class QnetVariant(C.Structure):
+    _fields_ = [("double_dqn", C.c_int32), ("is_weights", C.c_void_p), ("uniform_weight", C.c_void_p),
+                ("td_abs", C.c_void_p)]
 
 
 class EncCfg(C.Structure):
@@ -133,6 +138,8 @@ def _declare(lib):
     for name in ("porl_qnet_cql_backward", "porl_qnet_apply", "porl_qnet_learn"):
         getattr(lib, name).argtypes = [vp, C.POINTER(QnetHyper), vp]
     lib.porl_qnet_learn_indexed.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, i32, C.POINTER(QnetHyper), vp]
+    lib.porl_qnet_learn_variant.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp, i32, C.POINTER(QnetHyper),
+                                            C.POINTER(QnetVariant), vp]
     lib.porl_qnet_one_launch.argtypes = [vp]
     lib.porl_qnet_one_launch.restype = i32
     lib.porl_qnet_sync_target.argtypes = [vp, vp]

@@ -1233,7 +1233,8 @@ static int qnet_forward(porl_qnet* h, int nnets, const float* const* params, con
 // sum of the partial gradients (+ loss statistics)
 static int qnet_fused_backward(porl_qnet* h, const porl_qnet_hyper* hp, int B, const float* states, int64_t s_rs,
                                const float* next_states, int64_t n_rs, const int64_t* actions, const float* rew,
-                               const float* done, const int64_t* idx, hipStream_t s, bool with_adam = false) {
+                               const float* done, const int64_t* idx, hipStream_t s, bool with_adam = false,
+                               const porl_qnet_variant* var = nullptr) {
   float* W = h->buf.workspace;
   QnetFusedArgs a = h->fargs;
   a.params = h->buf.params; a.params_tgt = h->buf.params_tgt;
@@ -1245,6 +1246,7 @@ static int qnet_fused_backward(porl_qnet* h, const porl_qnet_hyper* hp, int B, c
   a.gamma = hp->gamma; a.alpha = hp->alpha; a.inv_batch = hp->inv_batch;
   a.log_A = (float)std::log((double)h->cfg.n_actions);
   a.stamps = g_qnet_stamps;
+  if (var) { a.double_dqn = var->double_dqn; a.is_w = var->is_weights; a.w_uniform = var->uniform_weight; a.td_abs = var->td_abs; }
   static bool attr_set = false;
   if (!attr_set) {
     PORL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1381,6 +1383,17 @@ int porl_qnet_learn_indexed(porl_qnet* h, const float* states, int64_t s_rs, con
               "minibatch and use porl_qnet_load_batch + porl_qnet_learn", QF_MAX_W, QF_MAX_LIN);
   return qnet_fused_backward(h, hp, batch, states, s_rs, next_states, n_rs, actions, rewards, dones, idx,
                              (hipStream_t)stream, true);
+}
+
+int porl_qnet_learn_variant(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions, const float* rewards,
+                            const float* next_states, int64_t n_rs, const float* dones, const int64_t* idx, int32_t batch,
+                            const porl_qnet_hyper* hp, const porl_qnet_variant* variant, void* stream) {
+  PORL_TRY(qnet_ready(h, false));
+  if (!hp || !states || !actions || !rewards || !next_states || !dones || !variant) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
+  if (!h->fused_ok || !g_qnet_fused) PORL_FAIL(PORL_ERR_UNSUPPORTED, "the DQN variants run on the one-launch kernel only");
+  return qnet_fused_backward(h, hp, batch, states, s_rs, next_states, n_rs, actions, rewards, dones, idx,
+                             (hipStream_t)stream, true, variant);
 }
 
 int porl_qnet_sync_target(porl_qnet* h, void* stream) {

@@ -38,6 +38,11 @@ struct QnetFusedArgs {
   int lds_tmp[2];                    // ping-pong: target-net activations, then dZ
   int lds_w;                         // one layer's weights, (round32(out), round4(in) + 4)
   float gamma, alpha, inv_batch, log_A;
+  // DQN variants on the same kernel (src/porl/train/dqn_per_trainer.py:75-123):
+  int double_dqn;                    // target = Q_tgt(s')[argmax_a Q_online(s', a)] instead of max_a Q_tgt(s', a)
+  const float* is_w;                 // (B,) per-sample loss weights (importance sampling), or null
+  const float* w_uniform;            // device scalar multiplying every sample's loss (null = 1)
+  float* td_abs;                     // (B,) |Q(s)[a] - target| for the priority write-back, or null
   unsigned long long* stamps;        // diagnostics: shader-clock stamps of block 0 at the phase boundaries, or null
 };
 
@@ -179,14 +184,18 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
   stamp();
   float4 wr[QF_WREGS];
   float br = 0.f;
+  const int n0 = a.double_dqn ? L + 1 : 0;          // stages of the leading online pass over s' (Double DQN)
+  const int n_stages = n0 + 3 * L + 2;
   auto stage = [&](int j, const float*& W, const float*& bias, int& N, int& K) {
-    const int l = j <= L ? j : (j <= 2 * L + 1 ? j - L - 1 : 3 * L + 2 - j);
-    const float* P = j <= L ? a.params_tgt : a.params;
+    const bool lead = j < n0;
+    if (!lead) j -= n0;
+    const int l = lead ? j : (j <= L ? j : (j <= 2 * L + 1 ? j - L - 1 : 3 * L + 2 - j));
+    const float* P = (!lead && j <= L) ? a.params_tgt : a.params;
     W = P + a.w_off[l]; bias = P + a.b_off[l];
     N = a.dims[l + 1]; K = a.dims[l];
   };
   auto fetch = [&](int j) {
-    if (j > 3 * L + 1) return;
+    if (j >= n_stages) return;
     const float* W; const float* bias; int N, K;
     stage(j, W, bias, N, K);
     qf_fetch_w(wr, br, W, bias, N, K, t);
@@ -202,10 +211,28 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
   // s' waits in tmp[1] (free until the target net's layer 1 writes there), s in the online net's input buffer
   float* Xn = qf_lds + a.lds_tmp[1];
   qf_load_inputs(Xn, X, ldx, a.next_states, a.n_rs, a.states, a.s_rs, a.idx, row0, a.B, a.dims[0], t);
+  __shared__ int amax[QF_ROWS];
+  if (a.double_dqn) {
+    // online net on s' in the (still unused) activation buffers of the main pass; only argmax_a survives
+    for (int l = 0; l <= L; ++l) {
+      park(l);
+      __syncthreads();
+      fetch(l + 1);
+      qf_forward(l == 0 ? Xn : qf_lds + a.lds_act[l], qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L,
+                 qf_lds + a.lds_act[l + 1], qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
+      __syncthreads();
+    }
+    if (t < QF_ROWS) {
+      const float* q = qf_lds + a.lds_act[L + 1] + t * (qf_r32(a.dims[L + 1]) + 4);
+      int best = 0;
+      for (int j = 1; j < a.dims[L + 1]; ++j) best = q[j] > q[best] ? j : best;     // first maximum, like torch.max
+      amax[t] = best;
+    }
+  }
   for (int l = 0; l <= L; ++l) {
-    park(l);
+    park(n0 + l);
     __syncthreads();
-    fetch(l + 1);
+    fetch(n0 + l + 1);
     const float* in = l == 0 ? Xn : qf_lds + a.lds_tmp[(l - 1) & 1];
     qf_forward(in, qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L,
                qf_lds + a.lds_tmp[l & 1], qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
@@ -217,9 +244,9 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
 
   // ---- online network on s, activations kept ------------------------------------------------------------
   for (int l = 0; l <= L; ++l) {
-    park(L + 1 + l);
+    park(n0 + L + 1 + l);
     __syncthreads();
-    fetch(L + 2 + l);
+    fetch(n0 + L + 2 + l);
     qf_forward(qf_lds + a.lds_act[l], qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L,
                qf_lds + a.lds_act[l + 1], qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
     __syncthreads();
@@ -244,14 +271,18 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
         const long src = a.idx ? a.idx[b] : (long)b;
         const int act = (int)a.actions[src];
         const float qa = q[act];
-        const float y = a.rew[src] + a.gamma * mxn * (1.f - a.done[src]);
+        const float qnext = a.double_dqn ? qn[amax[lane]] : mxn;
+        const float y = a.rew[src] + a.gamma * qnext * (1.f - a.done[src]);
         const float diff = qa - y;
-        td = diff * diff;
+        float wgt = a.is_w ? a.is_w[b] : 1.f;
+        if (a.w_uniform) wgt *= a.w_uniform[0];
+        td = wgt * (diff * diff);
         pen = lse - a.log_A - qa;
+        if (a.td_abs) a.td_abs[b] = fabsf(diff);
         const float ab = a.alpha * a.inv_batch;
         for (int j = 0; j < A; ++j) {
           float g = ab * expf(q[j] - lse);
-          if (j == act) g += 2.f * a.inv_batch * diff - ab;
+          if (j == act) g += 2.f * a.inv_batch * wgt * diff - ab;
           dq[j] = g;
         }
         for (int j = A; j < ldq; ++j) dq[j] = 0.f;
@@ -273,7 +304,7 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
     const int N = a.dims[l + 1], K = a.dims[l];
     const int lddz = qf_r32(N) + 4, ldin = qf_r32(K) + 4;
     const float* in = qf_lds + a.lds_act[l];
-    if (l > 0) park(3 * L + 2 - l);                                   // for dZ_{l-1}; nobody reads wl right now
+    if (l > 0) park(n0 + 3 * L + 2 - l);                                   // for dZ_{l-1}; nobody reads wl right now
     // dW_l = dZ^T . in over the block's 32 rows: tiles of 32 (n) x 32 (k), round-robin over the waves
     const int tiles_n = qf_r32(N) / 32, tiles_k = qf_r32(K) / 32;
     for (int tile = wave; tile < tiles_n * tiles_k; tile += 4) {
@@ -301,7 +332,7 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
     stamp();
     if (l == 0) break;
     __syncthreads();                                                  // wl is parked
-    fetch(3 * L + 3 - l);
+    fetch(n0 + 3 * L + 3 - l);
     // dZ_{l-1} = (dZ . W_l) * 1[in > 0]: 32-column slabs of K over the waves
     float* dzp = qf_lds + a.lds_tmp[l & 1];                           // dZ_l lives in tmp[(l + 1) & 1]
     const int ldw = qf_r4(K) + 4;

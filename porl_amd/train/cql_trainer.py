@@ -104,7 +104,7 @@ class QnetEngine:
     def apply(self, hp): N.check(self._lib.porl_qnet_apply(self._h, C.byref(hp), N.current_stream_ptr()), "porl_qnet_apply")
     def learn(self, hp): N.check(self._lib.porl_qnet_learn(self._h, C.byref(hp), N.current_stream_ptr()), "porl_qnet_learn")
 
-    def learn_indexed(self, hp, states, actions, rewards, next_states, dones, idx):
+    def learn_indexed(self, hp, states, actions, rewards, next_states, dones, idx, variant=None):
         """learn() on rows `idx` (int64, device) of device-resident replay arrays, gathered inside the step kernel.
         Raises NativeError(PORL_ERR_UNSUPPORTED) for networks the one-launch kernel does not cover."""
         self._ensure_bound()
@@ -118,9 +118,16 @@ class QnetEngine:
                 raise RuntimeError(f"{name}: need a contiguous {dt} tensor on {self.device}")
         if states.shape[1:].numel() != self.cfg.state_dim or next_states.shape != states.shape:
             raise RuntimeError("replay arrays do not match the network's state_dim")
-        N.check(self._lib.porl_qnet_learn_indexed(self._h, N.ptr(states), self.cfg.state_dim, N.ptr(actions), N.ptr(rewards),
-                                                  N.ptr(next_states), self.cfg.state_dim, N.ptr(dones), N.ptr(idx), B,
-                                                  C.byref(hp), N.current_stream_ptr()), "porl_qnet_learn_indexed")
+        if variant is None:
+            N.check(self._lib.porl_qnet_learn_indexed(self._h, N.ptr(states), self.cfg.state_dim, N.ptr(actions),
+                                                      N.ptr(rewards), N.ptr(next_states), self.cfg.state_dim, N.ptr(dones),
+                                                      N.ptr(idx), B, C.byref(hp), N.current_stream_ptr()),
+                    "porl_qnet_learn_indexed")
+        else:
+            N.check(self._lib.porl_qnet_learn_variant(self._h, N.ptr(states), self.cfg.state_dim, N.ptr(actions),
+                                                      N.ptr(rewards), N.ptr(next_states), self.cfg.state_dim, N.ptr(dones),
+                                                      N.ptr(idx), B, C.byref(hp), C.byref(variant),
+                                                      N.current_stream_ptr()), "porl_qnet_learn_variant")
         return B
 
     def sync_target(self):

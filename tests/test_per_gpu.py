@@ -71,3 +71,43 @@ def test_tree_invariants_at_scale():
     p = t[cap - 1:] / t[0]
     expect_heavy = 20 * 4096 * p[:10].sum()
     assert abs(hits[:10].sum() - expect_heavy) < 6 * np.sqrt(expect_heavy)
+
+
+def test_per_trainer_learn_matches_reference_golden():
+    """PERTrainer.learn (dqn_per_trainer.py:67-123): Double-DQN target, the reference's (B,1)x(B,) weighted loss,
+    Adam, priority write-back — four steps under the same `random` stream."""
+    from conftest import sub
+    from porl_amd.train.dqn_per_trainer import PERTrainer
+    from porl_amd.util.synth import make_discrete_transitions
+    z, _ = load_golden("per_trainer_s12_a5")
+    S, A, B, K, N, cap, seed_model, seed_data, seed_rand = (int(v) for v in z["meta"])
+    t = PERTrainer(S, A, float(z["gamma"]), device=DEV, batch_size=B, capacity=cap)
+    t.memory.beta_frames = 1000
+    t.q_network.load_state_dict({k: torch.from_numpy(v) for k, v in sub(z, "init/").items()})
+    t.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in sub(z, "init_target/").items()})
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=seed_data)
+    for i in range(N):
+        t.memory.add(1.0, st[i], int(ac[i]), float(rw[i]), ns[i], float(dn[i]))
+    random.seed(seed_rand)
+    for k in range(K):
+        np.testing.assert_allclose(t.learn(), z["loss"][k], rtol=2e-5)
+    got = {k: v.detach().cpu().numpy() for k, v in t.q_network.state_dict().items()}
+    for k, v in sub(z, "final/").items():
+        np.testing.assert_allclose(got[k], v, atol=1e-5, err_msg=k)
+    np.testing.assert_allclose(t.memory.tree.cpu().numpy(), z["tree_after"], rtol=2e-5, atol=5e-6)   # (|td|+eps)^0.6 of fp32 errors near 0
+
+
+def test_per_sample_weighting_changes_the_step():
+    from porl_amd.train.dqn_per_trainer import PERTrainer
+    from porl_amd.util.synth import make_discrete_transitions
+    S, A, B, N = 12, 5, 64, 300
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=1)
+    losses = []
+    for flag in (False, True):
+        torch.manual_seed(0)
+        t = PERTrainer(S, A, 0.99, device=DEV, batch_size=B, capacity=512, per_sample_weights=flag)
+        for i in range(N):
+            t.memory.add(0.1 + (i % 7), st[i], int(ac[i]), float(rw[i]), ns[i], float(dn[i]))
+        random.seed(3)
+        losses.append([t.learn() for _ in range(2)])
+    assert np.isfinite(losses).all() and abs(losses[0][0] - losses[1][0]) > 1e-6
