@@ -164,6 +164,104 @@ __device__ __forceinline__ void qf_forward(const float* in, int ldi, const float
   }
 }
 
+// ---- loss and dL/dQ: one lane per row  (cql_trainer.py:94-118; same arithmetic as cql_loss_kernel).  dq may be
+// the Q buffer itself: a lane reads q[j] before it writes dq[j].  Leaves the block's partial sums in red[0..1].
+__device__ __forceinline__ void qf_loss_rows(const QnetFusedArgs& a, const float* Q, const float* Qn, float* dz, const int* amax,
+                                             int row0, int lane, int wave, float* red) {
+  const int A = a.dims[a.n_lin], ldq = qf_r32(A) + 4;
+  if (wave == 0) {
+    float td = 0.f, pen = 0.f;
+    if (lane < QF_ROWS) {
+      const int b = row0 + lane;
+      float* dq = dz + lane * ldq;
+      if (b < a.B) {
+        const float* q = Q + lane * ldq;
+        const float* qn = Qn + lane * ldq;
+        float mx = -INFINITY, mxn = -INFINITY;
+        for (int j = 0; j < A; ++j) { mx = fmaxf(mx, q[j]); mxn = fmaxf(mxn, qn[j]); }
+        float se = 0.f;
+        for (int j = 0; j < A; ++j) se += expf(q[j] - mx);
+        const float lse = mx + logf(se);
+        const long src = a.idx ? a.idx[b] : (long)b;
+        const int act = (int)a.actions[src];
+        const float qa = q[act];
+        const float qnext = a.double_dqn ? qn[amax[lane]] : mxn;
+        const float y = a.rew[src] + a.gamma * qnext * (1.f - a.done[src]);
+        const float diff = qa - y;
+        float wgt = a.is_w ? a.is_w[b] : 1.f;
+        if (a.w_uniform) wgt *= a.w_uniform[0];
+        td = wgt * (diff * diff);
+        pen = lse - a.log_A - qa;
+        if (a.td_abs) a.td_abs[b] = fabsf(diff);
+        const float ab = a.alpha * a.inv_batch;
+        for (int j = 0; j < A; ++j) {
+          float g = ab * expf(q[j] - lse);
+          if (j == act) g += 2.f * a.inv_batch * wgt * diff - ab;
+          dq[j] = g;
+        }
+        for (int j = A; j < ldq; ++j) dq[j] = 0.f;
+      } else {
+        for (int j = 0; j < ldq; ++j) dq[j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { td += __shfl_xor(td, o); pen += __shfl_xor(pen, o); }
+    if (lane == 0) { red[0] = td; red[1] = pen; }
+  }
+}
+
+// dW_l = dZ^T . in over the block's 32 rows (32 x 32 tiles of (n, k), round-robin over the waves) and db_l = column
+// sums of dZ, written to the block's slab in the flat parameter layout
+__device__ __forceinline__ void qf_wgrad(const QnetFusedArgs& a, int l, const float* dz, const float* in, float* slab, int wave,
+                                         int li, int kh, int t) {
+  const int N = a.dims[l + 1], K = a.dims[l];
+  const int lddz = qf_r32(N) + 4, ldin = qf_r32(K) + 4;
+  const int tiles_n = qf_r32(N) / 32, tiles_k = qf_r32(K) / 32;
+  for (int tile = wave; tile < tiles_n * tiles_k; tile += 4) {
+    const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+    qf_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int s2 = 0; s2 < QF_ROWS / 2; ++s2) {
+      const int row = 2 * s2 + kh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[row * lddz + tn * 32 + li], in[row * ldin + tk * 32 + li], acc, 0, 0, 0);
+    }
+    const int k = tk * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (n < N && k < K) slab[a.w_off[l] + (long)n * K + k] = acc[r];
+    }
+  }
+  for (int n = t; n < N; n += 256) {
+    float s = 0.f;
+    for (int r = 0; r < QF_ROWS; ++r) s += dz[r * lddz + n];
+    slab[a.b_off[l] + n] = s;
+  }
+}
+
+// dZ_{l-1} = (dZ . W_l) * 1[in > 0]: 32-column slabs of K over the waves.  dzp may be `in` itself (the activation
+// is dead afterwards): a lane reads in[row][col] right before it writes dzp[row][col].
+__device__ __forceinline__ void qf_dgrad(const float* dz, int lddz, const float* wl, int N, int K, const float* in, int ldin,
+                                         float* dzp, int wave, int li, int kh) {
+  const int ldw = qf_r4(K) + 4, tiles_k = qf_r32(K) / 32;
+  for (int tk = wave; tk < tiles_k; tk += 4) {
+    qf_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int n0 = 0; n0 < qf_r32(N); n0 += 2) {
+      const int n = n0 + kh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[li * lddz + n], wl[n * ldw + tk * 32 + li], acc, 0, 0, 0);
+    }
+    const int col = tk * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      dzp[row * ldin + col] = (col < K && in[row * ldin + col] > 0.f) ? acc[r] : 0.f;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) {
   extern __shared__ float qf_lds[];
   __shared__ float red[2];
@@ -254,46 +352,7 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
 
   stamp();
   // ---- loss and dL/dQ: one lane per row  (cql_trainer.py:94-118; same arithmetic as cql_loss_kernel) ----
-  const int A = a.dims[L + 1], ldq = qf_r32(A) + 4;
-  if (wave == 0) {
-    float td = 0.f, pen = 0.f;
-    if (lane < QF_ROWS) {
-      const int b = row0 + lane;
-      float* dq = dz + lane * ldq;
-      if (b < a.B) {
-        const float* q = qf_lds + a.lds_act[L + 1] + lane * ldq;
-        const float* qn = Qn + lane * ldq;
-        float mx = -INFINITY, mxn = -INFINITY;
-        for (int j = 0; j < A; ++j) { mx = fmaxf(mx, q[j]); mxn = fmaxf(mxn, qn[j]); }
-        float se = 0.f;
-        for (int j = 0; j < A; ++j) se += expf(q[j] - mx);
-        const float lse = mx + logf(se);
-        const long src = a.idx ? a.idx[b] : (long)b;
-        const int act = (int)a.actions[src];
-        const float qa = q[act];
-        const float qnext = a.double_dqn ? qn[amax[lane]] : mxn;
-        const float y = a.rew[src] + a.gamma * qnext * (1.f - a.done[src]);
-        const float diff = qa - y;
-        float wgt = a.is_w ? a.is_w[b] : 1.f;
-        if (a.w_uniform) wgt *= a.w_uniform[0];
-        td = wgt * (diff * diff);
-        pen = lse - a.log_A - qa;
-        if (a.td_abs) a.td_abs[b] = fabsf(diff);
-        const float ab = a.alpha * a.inv_batch;
-        for (int j = 0; j < A; ++j) {
-          float g = ab * expf(q[j] - lse);
-          if (j == act) g += 2.f * a.inv_batch * wgt * diff - ab;
-          dq[j] = g;
-        }
-        for (int j = A; j < ldq; ++j) dq[j] = 0.f;
-      } else {
-        for (int j = 0; j < ldq; ++j) dq[j] = 0.f;
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { td += __shfl_xor(td, o); pen += __shfl_xor(pen, o); }
-    if (lane == 0) { red[0] = td; red[1] = pen; }
-  }
+  qf_loss_rows(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, row0, lane, wave, red);
   __syncthreads();
   if (t == 0) { a.part_td[blockIdx.x] = red[0]; a.part_pen[blockIdx.x] = red[1]; }
   stamp();
@@ -305,52 +364,14 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
     const int lddz = qf_r32(N) + 4, ldin = qf_r32(K) + 4;
     const float* in = qf_lds + a.lds_act[l];
     if (l > 0) park(n0 + 3 * L + 2 - l);                                   // for dZ_{l-1}; nobody reads wl right now
-    // dW_l = dZ^T . in over the block's 32 rows: tiles of 32 (n) x 32 (k), round-robin over the waves
-    const int tiles_n = qf_r32(N) / 32, tiles_k = qf_r32(K) / 32;
-    for (int tile = wave; tile < tiles_n * tiles_k; tile += 4) {
-      const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
-      qf_f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      for (int s2 = 0; s2 < QF_ROWS / 2; ++s2) {
-        const int row = 2 * s2 + kh;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[row * lddz + tn * 32 + li], in[row * ldin + tk * 32 + li], acc, 0, 0, 0);
-      }
-      const int k = tk * 32 + li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (n < N && k < K) slab[a.w_off[l] + (long)n * K + k] = acc[r];
-      }
-    }
-    // db_l = column sums of dZ
-    for (int n = t; n < N; n += 256) {
-      float s = 0.f;
-      for (int r = 0; r < QF_ROWS; ++r) s += dz[r * lddz + n];
-      slab[a.b_off[l] + n] = s;
-    }
+    qf_wgrad(a, l, dz, in, slab, wave, li, kh, t);
     stamp();
     if (l == 0) break;
     __syncthreads();                                                  // wl is parked
     fetch(n0 + 3 * L + 3 - l);
     // dZ_{l-1} = (dZ . W_l) * 1[in > 0]: 32-column slabs of K over the waves
     float* dzp = qf_lds + a.lds_tmp[l & 1];                           // dZ_l lives in tmp[(l + 1) & 1]
-    const int ldw = qf_r4(K) + 4;
-    for (int tk = wave; tk < tiles_k; tk += 4) {
-      qf_f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      for (int n0 = 0; n0 < qf_r32(N); n0 += 2) {
-        const int n = n0 + kh;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[li * lddz + n], wl[n * ldw + tk * 32 + li], acc, 0, 0, 0);
-      }
-      const int col = tk * 32 + li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-        dzp[row * ldin + col] = (col < K && in[row * ldin + col] > 0.f) ? acc[r] : 0.f;
-      }
-    }
+    qf_dgrad(dz, lddz, wl, N, K, in, ldin, dzp, wave, li, kh);
     __syncthreads();
     dz = dzp;
     stamp();
