@@ -1127,7 +1127,7 @@ int porl_qnet_create(const porl_qnet_cfg* c, porl_qnet** out) {
       }
       for (int l = 0; l <= L; ++l) {
         fa.w_off[l] = m.w[l]; fa.b_off[l] = m.b[l];
-        wmax = std::max(wmax, ((m.dims[l + 1] + 31) & ~31) * (((m.dims[l] + 3) & ~3) + 4));
+        wmax = std::max(wmax, ((m.dims[l + 1] + 31) & ~31) * (((m.dims[l] + 15) & ~15) + 4));
       }
       fa.lds_tmp[0] = off; off += QF_ROWS * (maxw + 4);
       fa.lds_tmp[1] = off; off += QF_ROWS * (maxw + 4);

@@ -50,6 +50,8 @@ typedef float qf_f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int qf_r32(int x) { return (x + 31) & ~31; }
 __device__ __forceinline__ int qf_r4(int x) { return (x + 3) & ~3; }
+// K extent of a weight image row: the MFMA loops run four k-steps (16 columns) per trip, zero padded
+__device__ __forceinline__ int qf_rk(int x) { return (x + 15) & ~15; }
 // i / d for 0 <= i < 2^16, 1 <= d <= 256 in three instructions (the half-unit margin dwarfs fp32 rounding)
 __device__ __forceinline__ int qf_div(int i, float inv_d) { return __float2int_rz(((float)i + 0.5f) * inv_d); }
 
@@ -90,7 +92,7 @@ __device__ __forceinline__ void qf_load_inputs(float* dst_n, float* dst_s, int l
 constexpr int QF_WREGS = (QF_MAX_W * (QF_MAX_W + 4) / 4 + 255) / 256;      // 17
 __device__ __forceinline__ void qf_fetch_w(float4 (&v)[QF_WREGS], float& bias_reg, const float* W, const float* bias, int N,
                                            int K, int t) {
-  const int ld4 = (qf_r4(K) + 4) >> 2, total4 = qf_r32(N) * ld4;
+  const int ld4 = (qf_rk(K) + 4) >> 2, total4 = qf_r32(N) * ld4;
   const float inv_ld4 = 1.0f / (float)ld4;
   const bool vec = (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0);
   // branch-free: every lane loads from a valid address and the result is selected afterwards — a branch around
@@ -124,7 +126,7 @@ __device__ __forceinline__ void qf_fetch_w(float4 (&v)[QF_WREGS], float& bias_re
 }
 __device__ __forceinline__ void qf_park_w(float* wl, float* bl, const float4 (&v)[QF_WREGS], float bias_reg, int N, int K,
                                           int t) {
-  const int total4 = qf_r32(N) * ((qf_r4(K) + 4) >> 2);
+  const int total4 = qf_r32(N) * ((qf_rk(K) + 4) >> 2);
   if (t < QF_MAX_W) bl[t] = bias_reg;
 #pragma unroll
   for (int u = 0; u < QF_WREGS; ++u) {
@@ -136,21 +138,27 @@ __device__ __forceinline__ void qf_park_w(float* wl, float* bl, const float4 (&v
 // out[32][ldo] = act(in[32][ldi] . Wl^T + bias): wave w computes the 32-column slabs w, w+4, ...
 __device__ __forceinline__ void qf_forward(const float* in, int ldi, const float* wl, int K, int N, const float* bias /* LDS */,
                                            bool relu, float* out, int ldo, int wave, int li, int kh) {
-  const int ldw = qf_r4(K) + 4, Kp = qf_r4(K);
+  const int ldw = qf_rk(K) + 4, Kp = qf_rk(K);        // activations are zero up to round32(K) >= round16(K)
   for (int tn = wave; tn < qf_r32(N) / 32; tn += 4) {
     qf_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* ap = in + li * ldi + 2 * kh;
     const float* bp = wl + (tn * 32 + li) * ldw + 2 * kh;
-    float2 a = *reinterpret_cast<const float2*>(ap), b = *reinterpret_cast<const float2*>(bp);
-    for (int k0 = 0; k0 < Kp; k0 += 4) {
-      // the rows have 4 floats of slack, so reading one step past the end stays inside the image
-      const float2 an = *reinterpret_cast<const float2*>(ap + k0 + 4);
-      const float2 bn = *reinterpret_cast<const float2*>(bp + k0 + 4);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-      a = an; b = bn;
+    // four k-steps per trip: the eight LDS reads are issued together and the MFMAs start as they land (a rolling
+    // one-step prefetch gets folded back by the compiler into read -> wait -> 2 MFMAs, ~2x slower)
+    for (int k0 = 0; k0 < Kp; k0 += 16) {
+      float2 av[4], bv4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        av[j] = *reinterpret_cast<const float2*>(ap + k0 + 4 * j);
+        bv4[j] = *reinterpret_cast<const float2*>(bp + k0 + 4 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, bv4[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, bv4[j].y, acc, 0, 0, 0);
+      }
     }
     const int col = tn * 32 + li;
     const float bv = bias[col];                    // zero past N
@@ -222,9 +230,16 @@ __device__ __forceinline__ void qf_wgrad(const QnetFusedArgs& a, int l, const fl
     qf_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int s2 = 0; s2 < QF_ROWS / 2; ++s2) {
-      const int row = 2 * s2 + kh;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[row * lddz + tn * 32 + li], in[row * ldin + tk * 32 + li], acc, 0, 0, 0);
+    for (int s2 = 0; s2 < QF_ROWS / 2; s2 += 4) {
+      float av[4], bv4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 2 * (s2 + j) + kh;
+        av[j] = dz[row * lddz + tn * 32 + li];
+        bv4[j] = in[row * ldin + tk * 32 + li];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv4[j], acc, 0, 0, 0);
     }
     const int k = tk * 32 + li;
 #pragma unroll
@@ -244,14 +259,21 @@ __device__ __forceinline__ void qf_wgrad(const QnetFusedArgs& a, int l, const fl
 // is dead afterwards): a lane reads in[row][col] right before it writes dzp[row][col].
 __device__ __forceinline__ void qf_dgrad(const float* dz, int lddz, const float* wl, int N, int K, const float* in, int ldin,
                                          float* dzp, int wave, int li, int kh) {
-  const int ldw = qf_r4(K) + 4, tiles_k = qf_r32(K) / 32;
+  const int ldw = qf_rk(K) + 4, tiles_k = qf_r32(K) / 32;
   for (int tk = wave; tk < tiles_k; tk += 4) {
     qf_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int n0 = 0; n0 < qf_r32(N); n0 += 2) {
-      const int n = n0 + kh;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[li * lddz + n], wl[n * ldw + tk * 32 + li], acc, 0, 0, 0);
+    for (int n0 = 0; n0 < qf_r32(N); n0 += 8) {
+      float av[4], bv4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 2 * j + kh;
+        av[j] = dz[li * lddz + n];
+        bv4[j] = wl[n * ldw + tk * 32 + li];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv4[j], acc, 0, 0, 0);
     }
     const int col = tk * 32 + li;
 #pragma unroll
