@@ -48,6 +48,13 @@ struct QnetFusedArgs {
 
 typedef float qf_f32x16 __attribute__((ext_vector_type(16)));
 
+// Workgroup barrier that retires LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait at the end
+// of every layer for the NEXT layer's weights (requested into registers just before the layer's MFMA work) — a full
+// round trip to L2 per layer.  Nothing in this kernel communicates through global memory between barriers.
+__device__ __forceinline__ void qf_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ int qf_r32(int x) { return (x + 31) & ~31; }
 __device__ __forceinline__ int qf_r4(int x) { return (x + 3) & ~3; }
 // K extent of a weight image row: the MFMA loops run four k-steps (16 columns) per trip, zero padded
@@ -140,9 +147,11 @@ __device__ __forceinline__ void qf_forward(const float* in, int ldi, const float
                                            bool relu, float* out, int ldo, int wave, int li, int kh) {
   const int ldw = qf_rk(K) + 4, Kp = qf_rk(K);        // activations are zero up to round32(K) >= round16(K)
   for (int tn = wave; tn < qf_r32(N) / 32; tn += 4) {
-    qf_f32x16 acc;
+    // two accumulators: a chain of dependent 32x32x2 MFMAs issues at half rate (the next one waits for the
+    // previous result), two interleaved chains fill the matrix pipe
+    qf_f32x16 acc, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
     const float* ap = in + li * ldi + 2 * kh;
     const float* bp = wl + (tn * 32 + li) * ldw + 2 * kh;
     // four k-steps per trip: the eight LDS reads are issued together and the MFMAs start as they land (a rolling
@@ -157,9 +166,11 @@ __device__ __forceinline__ void qf_forward(const float* in, int ldi, const float
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, bv4[j].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, bv4[j].y, acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, bv4[j].y, acc1, 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
     const int col = tn * 32 + li;
     const float bv = bias[col];                    // zero past N
 #pragma unroll
@@ -227,9 +238,9 @@ __device__ __forceinline__ void qf_wgrad(const QnetFusedArgs& a, int l, const fl
   const int tiles_n = qf_r32(N) / 32, tiles_k = qf_r32(K) / 32;
   for (int tile = wave; tile < tiles_n * tiles_k; tile += 4) {
     const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
-    qf_f32x16 acc;
+    qf_f32x16 acc, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
     for (int s2 = 0; s2 < QF_ROWS / 2; s2 += 4) {
       float av[4], bv4[4];
 #pragma unroll
@@ -239,8 +250,13 @@ __device__ __forceinline__ void qf_wgrad(const QnetFusedArgs& a, int l, const fl
         bv4[j] = in[row * ldin + tk * 32 + li];
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv4[j], acc, 0, 0, 0);
+      for (int j = 0; j < 4; j += 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv4[j], acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j + 1], bv4[j + 1], acc1, 0, 0, 0);
+      }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
     const int k = tk * 32 + li;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -261,9 +277,9 @@ __device__ __forceinline__ void qf_dgrad(const float* dz, int lddz, const float*
                                          float* dzp, int wave, int li, int kh) {
   const int ldw = qf_rk(K) + 4, tiles_k = qf_r32(K) / 32;
   for (int tk = wave; tk < tiles_k; tk += 4) {
-    qf_f32x16 acc;
+    qf_f32x16 acc, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
     for (int n0 = 0; n0 < qf_r32(N); n0 += 8) {
       float av[4], bv4[4];
 #pragma unroll
@@ -273,8 +289,13 @@ __device__ __forceinline__ void qf_dgrad(const float* dz, int lddz, const float*
         bv4[j] = wl[n * ldw + tk * 32 + li];
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv4[j], acc, 0, 0, 0);
+      for (int j = 0; j < 4; j += 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv4[j], acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j + 1], bv4[j + 1], acc1, 0, 0, 0);
+      }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
     const int col = tk * 32 + li;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -319,6 +340,9 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
     const float* W; const float* bias; int N, K;
     stage(j, W, bias, N, K);
     qf_fetch_w(wr, br, W, bias, N, K, t);
+    // compiler barrier: without it the loads are sunk below the layer's MFMA loop (nothing there depends on them),
+    // i.e. issued right before their first use, and every layer pays the full round trip to L2
+    asm volatile("" ::: "memory");
   };
   auto park = [&](int j) {
     const float* W; const float* bias; int N, K;
@@ -336,11 +360,11 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
     // online net on s' in the (still unused) activation buffers of the main pass; only argmax_a survives
     for (int l = 0; l <= L; ++l) {
       park(l);
-      __syncthreads();
+      qf_barrier();
       fetch(l + 1);
       qf_forward(l == 0 ? Xn : qf_lds + a.lds_act[l], qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L,
                  qf_lds + a.lds_act[l + 1], qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
-      __syncthreads();
+      qf_barrier();
     }
     if (t < QF_ROWS) {
       const float* q = qf_lds + a.lds_act[L + 1] + t * (qf_r32(a.dims[L + 1]) + 4);
@@ -351,12 +375,12 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
   }
   for (int l = 0; l <= L; ++l) {
     park(n0 + l);
-    __syncthreads();
+    qf_barrier();
     fetch(n0 + l + 1);
     const float* in = l == 0 ? Xn : qf_lds + a.lds_tmp[(l - 1) & 1];
     qf_forward(in, qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L,
                qf_lds + a.lds_tmp[l & 1], qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
-    __syncthreads();
+    qf_barrier();
   }
   stamp();
   const float* Qn = qf_lds + a.lds_tmp[L & 1];
@@ -365,17 +389,17 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
   // ---- online network on s, activations kept ------------------------------------------------------------
   for (int l = 0; l <= L; ++l) {
     park(n0 + L + 1 + l);
-    __syncthreads();
+    qf_barrier();
     fetch(n0 + L + 2 + l);
     qf_forward(qf_lds + a.lds_act[l], qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L,
                qf_lds + a.lds_act[l + 1], qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
-    __syncthreads();
+    qf_barrier();
   }
 
   stamp();
   // ---- loss and dL/dQ: one lane per row  (cql_trainer.py:94-118; same arithmetic as cql_loss_kernel) ----
   qf_loss_rows(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, row0, lane, wave, red);
-  __syncthreads();
+  qf_barrier();
   if (t == 0) { a.part_td[blockIdx.x] = red[0]; a.part_pen[blockIdx.x] = red[1]; }
   stamp();
 
@@ -389,12 +413,12 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
     qf_wgrad(a, l, dz, in, slab, wave, li, kh, t);
     stamp();
     if (l == 0) break;
-    __syncthreads();                                                  // wl is parked
+    qf_barrier();                                                  // wl is parked
     fetch(n0 + 3 * L + 3 - l);
     // dZ_{l-1} = (dZ . W_l) * 1[in > 0]: 32-column slabs of K over the waves
     float* dzp = qf_lds + a.lds_tmp[l & 1];                           // dZ_l lives in tmp[(l + 1) & 1]
     qf_dgrad(dz, lddz, wl, N, K, in, ldin, dzp, wave, li, kh);
-    __syncthreads();
+    qf_barrier();
     dz = dzp;
     stamp();
   }
