@@ -356,45 +356,31 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
   float* Xn = qf_lds + a.lds_tmp[1];
   qf_load_inputs(Xn, X, ldx, a.next_states, a.n_rs, a.states, a.s_rs, a.idx, row0, a.B, a.dims[0], t);
   __shared__ int amax[QF_ROWS];
-  if (a.double_dqn) {
-    // online net on s' in the (still unused) activation buffers of the main pass; only argmax_a survives
+  // Forward passes share ONE copy of the park / fetch / layer code (the kernel runs each instruction once per block,
+  // so its size is its instruction-fetch cost): pass 0 = online net on s' (Double DQN only, argmax kept),
+  // pass 1 = target net on s' (activations ping-pong in tmp), pass 2 = online net on s (activations kept).
+  int stage_no = 0;
+  for (int pass = a.double_dqn ? 0 : 1; pass < 3; ++pass) {
     for (int l = 0; l <= L; ++l) {
-      park(l);
+      park(stage_no);
       qf_barrier();
-      fetch(l + 1);
-      qf_forward(l == 0 ? Xn : qf_lds + a.lds_act[l], qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L,
-                 qf_lds + a.lds_act[l + 1], qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
+      fetch(stage_no + 1);
+      ++stage_no;
+      const float* in = l == 0 ? (pass == 2 ? X : Xn) : (pass == 1 ? qf_lds + a.lds_tmp[(l - 1) & 1] : qf_lds + a.lds_act[l]);
+      float* out = pass == 1 ? qf_lds + a.lds_tmp[l & 1] : qf_lds + a.lds_act[l + 1];
+      qf_forward(in, qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L, out, qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
       qf_barrier();
     }
-    if (t < QF_ROWS) {
+    if (pass == 0 && t < QF_ROWS) {
       const float* q = qf_lds + a.lds_act[L + 1] + t * (qf_r32(a.dims[L + 1]) + 4);
       int best = 0;
       for (int j = 1; j < a.dims[L + 1]; ++j) best = q[j] > q[best] ? j : best;     // first maximum, like torch.max
       amax[t] = best;
     }
+    if (pass == 1) stamp();
   }
-  for (int l = 0; l <= L; ++l) {
-    park(n0 + l);
-    qf_barrier();
-    fetch(n0 + l + 1);
-    const float* in = l == 0 ? Xn : qf_lds + a.lds_tmp[(l - 1) & 1];
-    qf_forward(in, qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L,
-               qf_lds + a.lds_tmp[l & 1], qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
-    qf_barrier();
-  }
-  stamp();
   const float* Qn = qf_lds + a.lds_tmp[L & 1];
   float* dz = qf_lds + a.lds_tmp[(L + 1) & 1];
-
-  // ---- online network on s, activations kept ------------------------------------------------------------
-  for (int l = 0; l <= L; ++l) {
-    park(n0 + L + 1 + l);
-    qf_barrier();
-    fetch(n0 + L + 2 + l);
-    qf_forward(qf_lds + a.lds_act[l], qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L,
-               qf_lds + a.lds_act[l + 1], qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
-    qf_barrier();
-  }
 
   stamp();
   // ---- loss and dL/dQ: one lane per row  (cql_trainer.py:94-118; same arithmetic as cql_loss_kernel) ----
