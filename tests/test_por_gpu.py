@@ -306,3 +306,22 @@ def test_stats_redirection_keeps_a_device_loss_history():
         agent.por_residual_update(s, sp, r, d)
         want.append(ref.por_residual_update(s, sp, r, d))
     np.testing.assert_array_equal(hist[:, :2].cpu().numpy(), np.array(want, dtype=np.float32))
+
+
+def test_por_global_batch_of_config4_on_one_gpu():
+    """B=8192 (the global batch of BASELINE config 4) in one engine: losses and all 5.6 M parameters after one
+    update against the fp64 oracle; exercises workspace sizing, split-K choices and reductions at 8x the headline
+    batch, and the 1/B scaling the data-parallel mode relies on."""
+    S, H, L, B = 60, 1024, 2, 8192
+    agent = _make_por(S, H, L, B)
+    o = _oracle64(_np_sd(agent), S, H, L, False)
+    rows_np = make_rows(B, S, 2, seed=41).astype(np.float64)
+    rows = torch.from_numpy(rows_np.astype(np.float32)).to(DEV)
+    s, r, sp, d, a = split_rows(rows, S, 2)
+    vl, gl = agent.por_residual_update(s, sp, r, d)
+    sn, rn, spn, dn, _ = split_rows(rows_np, S, 2)
+    vo, go = o.por_residual_update(sn, spn, rn, dn)
+    np.testing.assert_allclose([vl, gl], [vo, go], rtol=LOSS_RTOL)
+    # the first Adam step is lr * g / (|g| + 1e-8): for the handful of weights whose gradient is ~1e-8 the fp32 noise
+    # of an 8192-row sum decides the sign, so a single element may be off by up to 2 * lr = 2e-4
+    _cmp_params_robust(_np_sd(agent), o.P, max_tol=2.1e-4)
