@@ -133,6 +133,9 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
 int porl_iql_value_apply(porl_iql* h, const porl_iql_hyper* hp, void* stream);
 /* por.py:97-108 — second twin forward with the updated vf, advantage weights, policy forward,
  * weighted NLL, backward.  Leaves grads_pol, stats[1] = g_loss share, stats[2] = min NLL. */
+/* optional, before porl_iql_policy_backward on the same batch: the policy MLP's forward (independent of the value
+ * networks), e.g. while the value-gradient all-reduce is in flight; policy_backward then skips it */
+int porl_iql_policy_prefetch(porl_iql* h, void* stream);
 int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream);
 /* por.py:109 — Adam on the policy (lr = hp->policy_lr). */
 int porl_iql_policy_apply(porl_iql* h, const porl_iql_hyper* hp, void* stream);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "porl_iql_tensor_info", "porl_iql_workspace_floats", "porl_iql_bind", "porl_iql_load_batch",
     "porl_iql_load_batch_sampled", "porl_iql_set_stats",
     "porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_backward",
-    "porl_iql_policy_apply", "porl_iql_step", "porl_iql_forward_value", "porl_iql_forward_policy",
+    "porl_iql_policy_apply", "porl_iql_step", "porl_iql_policy_prefetch", "porl_iql_forward_value", "porl_iql_forward_policy",
     "porl_gemm_f32", "porl_adam_ema", "porl_gather_rows", "porl_sample_indices", "porl_epoch_indices", "porl_per_update", "porl_per_sample",
     "porl_prof_enable", "porl_prof_read", "porl_tune_set", "porl_tune_set_ptr", "porl_state2costmap",
     "porl_qnet_create", "porl_qnet_destroy", "porl_qnet_param_floats", "porl_qnet_tensors",
@@ -110,6 +110,7 @@ def _declare(lib):
     for name in ("porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_backward",
                  "porl_iql_policy_apply", "porl_iql_step"):
         getattr(lib, name).argtypes = [vp, C.POINTER(IqlHyper), vp]
+    lib.porl_iql_policy_prefetch.argtypes = [vp, vp]
     lib.porl_iql_forward_value.argtypes = [vp, C.c_int, vp, i64, i32, vp, vp, vp]
     lib.porl_iql_forward_policy.argtypes = [vp, vp, i64, i32, vp, i64, vp]
     lib.porl_gemm_f32.argtypes = [C.c_int, C.c_int, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, C.c_int,

@@ -177,9 +177,13 @@ class IqlAgentBase(nn.Module):
         else:
             # replay sharded across ranks: each rank's gradients carry 1/B_global, so SUM == global mean
             eng.value_backward(hp)
-            ex.allreduce_sum_(eng.grads_vf)
-            eng.value_apply(hp)
+            work = ex.allreduce_sum_async(eng.grads_vf)
             self.flush()                       # policy Adam of the PREVIOUS update, if its exchange was deferred
+            if pol_target is not None or replay is not None:
+                eng.policy_prefetch()          # policy MLP forward needs no value net: runs under the all-reduce
+            if work is not None:
+                work.wait()
+            eng.value_apply(hp)
             eng.policy_backward(hp)
             if self.async_losses:
                 # Nothing reads the policy before the next update's policy phase: start its gradient exchange

@@ -151,6 +151,8 @@ struct porl_iql {
   bool bound = false;
   int batch = 0;
   bool have_pol_target = false;
+  bool pol_prefetched = false;      // porl_iql_policy_prefetch ran for the loaded batch: policy forward is done
+  int pol_nslab = 1;
   int Sp = 0, Dp = 0, Hp = 0, parts_max = 0;
   Workspace ws{};
 };
@@ -404,6 +406,7 @@ int porl_iql_load_batch(porl_iql* h, int32_t batch, const float* obs, int64_t ob
   job(term, term_rs, W + h->ws.term, 1, 1);
   if (pol_target) job(pol_target, pt_rs, W + h->ws.xt, h->cfg.pol_out_dim, h->Dp);
   h->have_pol_target = pol_target != nullptr;
+  h->pol_prefetched = false;
   const long n = (long)batch * std::max(h->Sp, h->Dp);
   dim3 grid((unsigned)std::min<long>((n + 255) / 256, 1024), a.njobs);
   hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -508,6 +511,7 @@ int porl_iql_load_batch_sampled(porl_iql* h, int32_t batch, const float* rows, i
   PORL_HIP(hipGetLastError());
   h->batch = batch;
   h->have_pol_target = true;
+  h->pol_prefetched = false;
   return PORL_OK;
 }
 
@@ -690,6 +694,30 @@ static int policy_mean_slabs(porl_iql* h, int B, int* nslab, hipStream_t s) {
   return launch_group(g, tile, s);
 }
 
+// The part of the policy step that does not depend on the value networks: the policy MLP's forward on the loaded
+// observations.  In data-parallel mode it runs while the value-gradient all-reduce is on the wire.
+int porl_iql_policy_prefetch(porl_iql* h, void* stream) {
+  PORL_TRY(check_ready(h, true));
+  if (!h->have_pol_target) PORL_FAIL(PORL_ERR_INVALID, "policy step needs pol_target in porl_iql_load_batch");
+  hipStream_t s = (hipStream_t)stream;
+  const int B = h->batch, S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden;
+  float* W = h->buf.workspace;
+  const Workspace& ws = h->ws;
+  const float* Pp = h->buf.params_pol;
+  int parts = 0;
+  for (int l = 0; l < L; ++l) {
+    FwdNet f{};
+    if (l == 0) { f.in = W + ws.xs; f.ldin = h->Sp; }
+    else { f.in = W + ws.act_p[l - 1]; f.ldin = h->Hp; }
+    f.W = Pp + h->pol.w[l]; f.b = Pp + h->pol.b[l];
+    f.out = W + ws.act_p[l]; f.headw = nullptr; f.headout = nullptr;
+    PORL_TRY(fwd_hidden_layer(h, &f, 1, B, l == 0 ? S : H, l == L - 1, &parts, s));
+  }
+  PORL_TRY(policy_mean_slabs(h, B, &h->pol_nslab, s));
+  h->pol_prefetched = true;
+  return PORL_OK;
+}
+
 int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
   PORL_TRY(check_ready(h, true));
   if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
@@ -705,7 +733,10 @@ int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream
   int parts = 0;
   const bool LN = h->cfg.layer_norm != 0;
 
-  // -- forward: updated twins (head only) + policy hidden layers, 3 nets per launch ----------------
+  // -- forward: updated twins (head only) + policy hidden layers, 3 nets per launch; the policy net is left out
+  //    when porl_iql_policy_prefetch already ran it for this batch (data-parallel mode) ----------------------
+  const bool pre = h->pol_prefetched;
+  h->pol_prefetched = false;
   for (int l = 0; l < L; ++l) {
     FwdNet nets[3];
     const int K = l == 0 ? S : H;
@@ -724,10 +755,10 @@ int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream
     else { f.in = W + ws.act_p[l - 1]; f.ldin = Hp; }
     f.W = Pp + h->pol.w[l]; f.b = Pp + h->pol.b[l];
     f.out = W + ws.act_p[l]; f.headw = nullptr; f.headout = nullptr;
-    PORL_TRY(fwd_hidden_layer(h, nets, 3, B, K, last, &parts, s));
+    PORL_TRY(fwd_hidden_layer(h, nets, pre ? 2 : 3, B, K, last, &parts, s));
   }
-  int nslab = 1;
-  PORL_TRY(policy_mean_slabs(h, B, &nslab, s));
+  int nslab = h->pol_nslab;
+  if (!pre) PORL_TRY(policy_mean_slabs(h, B, &nslab, s));
 
   // -- advantage weights, NLL, dL/dmean, dL/dlog_std --------------------------------------------------
   const int nblk = cdiv(B, NLL_ROWS_PER_BLOCK);

@@ -165,6 +165,9 @@ class IqlEngine:
     def policy_apply(self, hp): self._phase("porl_iql_policy_apply", hp)
     def step(self, hp): self._phase("porl_iql_step", hp)
 
+    def policy_prefetch(self):
+        N.check(self._lib.porl_iql_policy_prefetch(self._h, N.current_stream_ptr()), "porl_iql_policy_prefetch")
+
     # -- forward-only ------------------------------------------------------------------------------
     def forward_value(self, x, target=False):
         self._ensure_bound()
