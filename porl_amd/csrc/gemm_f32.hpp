@@ -58,6 +58,10 @@ struct GemmProb {
   const float* rscale;    // per-sample factor of the residual form (null = 1)
   float* cstat;           // ((M+31)/32, 2, N): per 32-row block, column sums and sums of squares of the stored C
   int rs_rows, rs_row0;
+  // k-contiguous A whose rows are gathered 2x2 patches of an NHWC tensor (PatchMerging, agent/fasternet.py:253) instead
+  // of a dense (M, K) matrix: row m starts at (m * lda + (m / a_grp) * a_grp_jump) floats, and columns at or beyond
+  // a_seg_tiles K-tiles continue a_seg_jump floats further (the second image row of the patch).  a_grp == 0: dense.
+  int a_grp, a_grp_jump, a_seg_tiles, a_seg_jump;
   int M, N, K;
   int lda, ldb, ldc, ldmask;
   int act;
@@ -213,11 +217,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
   const size_t a_step = a_kc ? (size_t)BK : (size_t)BK * P.lda;   // pointer advance per K-tile
   const size_t b_step = b_kc ? (size_t)BK : (size_t)BK * P.ldb;
   // buffer resources over the whole operands and the scalar byte offset of K-tile kt
-  const BufRsrc a_rsrc = make_rsrc(Ag, (size_t)(a_kc ? M : P.K) * P.lda * sizeof(float));
+  const size_t a_rows_ext = P.a_grp > 0 ? (size_t)M + (size_t)(M / P.a_grp + 1) * (size_t)(P.a_grp_jump / P.lda + 1) +
+                                              (size_t)(P.a_seg_jump / P.lda + 1)
+                                        : (size_t)(a_kc ? M : P.K);
+  const BufRsrc a_rsrc = make_rsrc(Ag, a_rows_ext * P.lda * sizeof(float));
   const BufRsrc b_rsrc = make_rsrc(Bg, (size_t)(b_kc ? N : P.K) * P.ldb * sizeof(float));
   const unsigned a_org = (unsigned)((a_kc ? (size_t)ks : (size_t)ks * P.lda) * sizeof(float));
   const unsigned b_org = (unsigned)((b_kc ? (size_t)ks : (size_t)ks * P.ldb) * sizeof(float));
-  auto a_soff = [&](int kt) { return a_org + (unsigned)(kt * a_step * sizeof(float)); };
+  const int a_seg_tiles = P.a_grp > 0 ? P.a_seg_tiles : 0x7fffffff;
+  const unsigned a_seg_jump = (unsigned)((size_t)P.a_seg_jump * sizeof(float));
+  auto a_soff = [&](int kt) {
+    return a_org + (unsigned)(kt * a_step * sizeof(float)) + (kt >= a_seg_tiles ? a_seg_jump : 0u);
+  };
   auto b_soff = [&](int kt) { return b_org + (unsigned)(kt * b_step * sizeof(float)); };
 #pragma unroll
   for (int i = 0; i < NLA; ++i) {
@@ -225,7 +236,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
     if (a_kc) {
       const int kq = f % (BK / 4), row = f / (BK / 4);
       sa[i].kpos = ks + kq * 4; sa[i].cpos = m0 + row; sa[i].lds = row * SK + kq * 4;
-      sa[i].off = (unsigned)(((size_t)(m0 + row) * P.lda + kq * 4) * sizeof(float));
+      const size_t grp = P.a_grp > 0 ? (size_t)((m0 + row) / P.a_grp) * P.a_grp_jump : 0;
+      sa[i].off = (unsigned)(((size_t)(m0 + row) * P.lda + grp + kq * 4) * sizeof(float));
     } else {
       const int c4 = f % (BM / 4), kr = f / (BM / 4);
       sa[i].kpos = ks + kr; sa[i].cpos = m0 + c4 * 4; sa[i].lds = kr * SA + c4 * 4;

@@ -234,3 +234,24 @@ def test_sparse_patch_embedding_equals_the_dense_one():
     assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][1], z["state_after"])
     for k in outs[0][2]:
         np.testing.assert_allclose(outs[0][2][k], outs[1][2][k], rtol=1e-6, atol=1e-12)
+
+
+def test_merge_conv_gathers_its_patches_in_the_gemm():
+    """PatchMerging through the GEMM's grouped-row operand addressing (no space_to_depth copy) against the
+    materialised patch matrix: same k order, so the features are bit-identical; B=40 spans image-row groups,
+    samples and a ragged last tile."""
+    from porl_amd import engine as E
+    rng = np.random.default_rng(5)
+    st = np.empty((40, 362), dtype=np.float32)
+    st[:, :360] = rng.uniform(0.2, 3.9, size=(40, 360))
+    st[:, 360:] = rng.uniform(-3, 3, size=(40, 2))
+    outs = []
+    for s2d in (0, 1):
+        try:
+            E.tune_set("enc_s2d", s2d)
+            m = build(3, max_batch=40)
+            m.train()
+            outs.append(m(torch.from_numpy(st.copy()).to(DEV), drop_scale=torch.ones(3, 40)))
+        finally:
+            E.tune_set("enc_s2d", 0)
+    assert torch.equal(outs[0], outs[1])
