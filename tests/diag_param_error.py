@@ -1,4 +1,5 @@
-"""Diagnostic (GPU): where do HIP-vs-oracle parameter differences at H=1024 come from?
+"""Diagnostic (GPU, run by hand: python tests/diag_param_error.py; not collected by pytest): where do HIP-vs-oracle
+parameter differences at H=1024 come from?
 Compares engine fp32, oracle fp32 and oracle fp64 after K updates."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
