@@ -17,7 +17,7 @@ What is pinned:
   fasternet_*: FasterNet(3, 256).forward_cls (/root/reference/agent/fasternet.py:428-438) in eval mode and in
             train mode (batch-stat BatchNorm, running-stat update, DropPath masks replayed from the seed)
   sorl_enc_*: SORL.update with the FasterNet backbone (/root/reference/agent/sorl.py:78-128)
-  per_*   : PrioritizedReplayBuffer.add/sample/update_priorities under random.seed; per_trainer_*: PERTrainer.learn
+  per_*   : PrioritizedReplayBuffer.add/sample/update_priorities under random.seed; per_trainer_*: PERTrainer.learn; dqn_* / ddqn_*: DQNTrainer.learn / DDQNTrainer.learn
             (/root/reference/src/porl/train/dqn_per_trainer.py:67-123)
             (/root/reference/src/porl/buffer/prioritized_replay_buffer.py:36-108, sum_tree.py:4-77)
 
@@ -480,6 +480,41 @@ def gen_per_trainer(name, S=12, A=5, B=64, K=4, N=400, cap=512, seed_model=2, se
     print(f"{name}: loss={losses}")
 
 
+def gen_dqn(name, double, S=10, A=6, B=64, K=5, N=500, seed_model=4, seed_data=29, seed_np=3, gamma=0.99):
+    """DQNTrainer.learn (src/porl/train/dqn_trainer.py:93-118) / DDQNTrainer.learn (ddqn_trainer.py:58-99) as unbound
+    methods on a hand-built object; the numpy index stream is pinned by np.random.seed."""
+    _stub_cql_imports()
+    from porl.train.dqn_trainer import DQNTrainer
+    from porl.train.ddqn_trainer import DDQNTrainer
+    from porl.net.q_network import QNetwork
+    from porl.buffer.replaybuffer import ReplayBuffer
+    cls = DDQNTrainer if double else DQNTrainer
+    dev = torch.device("cpu")
+    torch.manual_seed(seed_model)
+    t = object.__new__(cls)
+    t.q_network = QNetwork(S, A).to(dev)
+    t.target_network = QNetwork(S, A).to(dev)
+    t.target_network.load_state_dict(t.q_network.state_dict())
+    with torch.no_grad():
+        for p in t.target_network.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    t.optimizer = torch.optim.Adam(t.q_network.parameters(), lr=0.0005)
+    t.replay_buffer = ReplayBuffer(N, (S,), dev)
+    t.batch_size, t.gamma, t.device = B, gamma, dev
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=seed_data)
+    for i in range(N):
+        t.replay_buffer.push(st[i], int(ac[i]), float(rw[i]), ns[i], bool(dn[i]))
+    out = {"meta": np.array([S, A, B, K, N, seed_model, seed_data, seed_np, int(double)]), "gamma": np.float64(gamma)}
+    out.update(pack("init/", sd_np(t.q_network)))
+    out.update(pack("init_target/", sd_np(t.target_network)))
+    np.random.seed(seed_np)
+    losses = [cls.learn(t) for _ in range(K)]
+    out["loss"] = np.array(losses, dtype=np.float64)
+    out.update(pack("final/", sd_np(t.q_network)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={losses}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -510,6 +545,8 @@ def main():
     # prioritized replay (next row)
     gen_per("per_cap300")
     gen_per_trainer("per_trainer_s12_a5")
+    gen_dqn("dqn_s10_a6", double=False)
+    gen_dqn("ddqn_s10_a6", double=True)
 
 
 if __name__ == "__main__":
