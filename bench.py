@@ -238,6 +238,40 @@ def bench_sorl_enc(a):
     print(json.dumps(out), flush=True)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without torchrun: start N rank processes (one GPU each) from a parent that makes
+    no HIP call at all — children are fresh interpreters (subprocess, no fork of GPU state, no re-exec) — relay
+    rank 0's JSON line and exit with the worst child code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):    # a dead rank would leave the others in a collective
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                  # exactly the PIDs started above
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    codes = [p.returncode for p in procs]
+    sys.stdout.write("".join(out0))
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"rank exit codes {codes}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="por", choices=["por", "cql", "sorl_enc"])
@@ -253,6 +287,8 @@ def main():
         return bench_cql(a)
     if a.workload == "sorl_enc":
         return bench_sorl_enc(a)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a.gpus)          # bare `python bench.py --gpus N`: this process never touches a GPU
 
     import numpy as np
     import torch
@@ -263,8 +299,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # PORL_BENCH_BACKEND=gloo rehearses the N>1 code path with several ranks on ONE GPU (no RCCL, no timing claim)
     backend = os.environ.get("PORL_BENCH_BACKEND", "nccl")
@@ -320,6 +355,15 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if world > 1:
+        # async mode keeps per-rank SHARES of the batch means in the history: one reduction after the timed
+        # loop makes them the global-batch statistics (sum of shares; minimum of the per-rank minima)
+        sums = losses[:, 0:2].contiguous()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        losses[:, 0:2] = sums
+        mins = losses[:, 2].contiguous()
+        dist.all_reduce(mins, op=dist.ReduceOp.MIN)
+        losses[:, 2] = mins
     lh = losses[:, :3].cpu().numpy()
     if not np.isfinite(lh).all():
         raise SystemExit("non-finite loss in the benchmark run")
@@ -332,23 +376,38 @@ def main():
             one_step(a.warmup + i)
         prof = E.prof_read()
         E.prof_enable(False)
-        gemms = [p for p in prof if p["name"].startswith("gemm_f32_kernel") and p["launches"]]
+        # profile labels are "<launch of the step>:<kernel>"; the roofline is quoted per KERNEL (all its launches)
+        by_kernel = {}
+        for p in prof:
+            if not p["launches"]:
+                continue
+            k = by_kernel.setdefault(p["name"].split(":")[-1].split(".")[-1], dict(launches=0, total_ms=0.0, flops=0.0))
+            for f in ("launches", "total_ms", "flops"):
+                k[f] += p[f]
+        gemms = {n: k for n, k in by_kernel.items() if n.startswith("gemm_f32_kernel")}
         if gemms:
-            dom = max(gemms, key=lambda p: p["total_ms"])
+            name, dom = max(gemms.items(), key=lambda kv: kv[1]["total_ms"])
             avg_ms = dom["total_ms"] / dom["launches"]
             flops_per_launch = dom["flops"] / dom["launches"]
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/), if present
-            try:
-                tj = json.load(open(os.path.join(REPO, "profiles", "r01_hbm_traffic.json")))
-                traffic = tj["kernels"][dom["name"]]["hbm_bytes_per_launch"]
-            except Exception:
-                pass
-            roof = dict(bound="mfma", kernel=dom["name"], achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=traffic,
+            # HBM bytes per launch are NOT measured by this run: they come from the committed rocprofv3 --pmc passes
+            # over this same command (separate passes, as the microarch guide prescribes); the source file is named
+            traffic, traffic_src = None, None
+            for fname in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+                try:
+                    tj = json.load(open(os.path.join(REPO, "profiles", fname)))
+                    traffic = tj["kernels"][name]["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/" + fname
+                    break
+                except Exception:
+                    pass
+            roof = dict(bound="mfma", kernel=name, achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src,
                         avg_launch_us=avg_ms * 1e3, launches=dom["launches"],
                         flop_per_launch=flops_per_launch,
-                        all_kernels_ms_per_step={p["name"]: p["total_ms"] / a.steps for p in prof if p["launches"]})
+                        launches_per_step=sum(p["launches"] for p in prof) / a.steps,
+                        # every launch of one update, HIP-event timed on the launch stream (instrumented pass)
+                        step_launches_us={p["name"]: round(1e3 * p["total_ms"] / a.steps, 2) for p in prof if p["launches"]})
 
     if rank == 0:
         steps_per_s = a.steps / elapsed
@@ -368,7 +427,9 @@ def main():
             "optimizer_steps_per_sec": steps_per_s,
             "samples_per_sec": steps_per_s * B * world,
             "algorithmic_tflops": steps_per_s * B * world * por_flops_per_sample() / 1e12,
-            "final_losses": {"v_loss": float(lh[-1, 0]), "g_loss": float(lh[-1, 1])},
+            "final_losses": {"v_loss": float(lh[-1, 0]), "g_loss": float(lh[-1, 1]), "min_nll": float(lh[-1, 2])},
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "backend": (dist.get_backend() if world > 1 else "none"),
         }
         if roof:
             out["roofline"] = roof

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define PORL_ABI_VERSION 2
+#define PORL_ABI_VERSION 3
 #define PORL_MAX_HIDDEN 8
 
 #define PORL_OK 0
@@ -104,6 +104,20 @@ int porl_iql_load_batch(porl_iql* h, int32_t batch,
 int porl_iql_load_batch_sampled(porl_iql* h, int32_t batch, const float* rows, int64_t row_stride,
                                 int64_t n_rows, int32_t act_dim, int32_t target_is_action,
                                 uint64_t seed, uint64_t step, int64_t* idx_out, void* stream);
+
+/* Execution mode of the phase calls (default 0).
+ *   PORL_IQL_MODE_TWO_SLOTS   : the minibatch staging buffers the policy phase reads (s, policy target, TD target)
+ *       exist twice and every porl_iql_load_batch* call flips to the other copy.  The policy phase of update t may
+ *       then run on a second stream while update t+1 is loaded and its value phase runs: the caller orders
+ *       value_apply(t) -> policy_backward(t) and policy_apply(t) -> value_apply(t+1) with events (the policy phase
+ *       reads the value parameters of update t; everything else it touches is private to it).  The reference runs
+ *       the two phases back to back (agent/por.py:81-110); results are identical, only completion order differs.
+ *   PORL_IQL_MODE_FOLD_COMBINE: *_backward leaves its split-K slabs / per-block partial sums uncombined and
+ *       *_apply combines them inside the Adam launch (one launch less per phase).  grads_* are complete only after
+ *       *_apply; a data-parallel caller that all-reduces grads_* between the two calls must not set it. */
+#define PORL_IQL_MODE_TWO_SLOTS 1
+#define PORL_IQL_MODE_FOLD_COMBINE 2
+int porl_iql_set_mode(porl_iql* h, int32_t mode);
 
 /* Redirect where the next updates write their 3 loss statistics (>= 8 floats, 16-byte aligned): lets a
  * training loop keep a device-side loss history without copies or host syncs. */

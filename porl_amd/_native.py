@@ -11,14 +11,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libporl_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/porl_hip.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
     "porl_abi_version", "porl_last_error",
     "porl_iql_create", "porl_iql_destroy", "porl_iql_group_floats", "porl_iql_group_tensors",
     "porl_iql_tensor_info", "porl_iql_workspace_floats", "porl_iql_bind", "porl_iql_load_batch",
-    "porl_iql_load_batch_sampled", "porl_iql_set_stats",
+    "porl_iql_load_batch_sampled", "porl_iql_set_stats", "porl_iql_set_mode",
     "porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_backward",
     "porl_iql_policy_apply", "porl_iql_step", "porl_iql_policy_prefetch", "porl_iql_forward_value", "porl_iql_forward_policy",
     "porl_gemm_f32", "porl_adam_ema", "porl_gather_rows", "porl_sample_indices", "porl_epoch_indices", "porl_per_update", "porl_per_sample",
@@ -107,6 +107,7 @@ def _declare(lib):
     lib.porl_iql_load_batch.argtypes = [vp, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp]
     lib.porl_iql_load_batch_sampled.argtypes = [vp, i32, vp, i64, i64, i32, i32, C.c_uint64, C.c_uint64, vp, vp]
     lib.porl_iql_set_stats.argtypes = [vp, vp]
+    lib.porl_iql_set_mode.argtypes = [vp, i32]
     for name in ("porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_backward",
                  "porl_iql_policy_apply", "porl_iql_step"):
         getattr(lib, name).argtypes = [vp, C.POINTER(IqlHyper), vp]
@@ -197,6 +198,10 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def current_stream_ptr():
+def current_stream_ptr(device=None):
+    """torch's current stream ON `device` (a torch.device / tensor / None = the thread's current device).  The C
+    entry points switch to the device that owns their buffers themselves; the stream must belong to that device."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if device is not None and not isinstance(device, torch.device):
+        device = device.device
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -48,6 +48,7 @@ class ArenaAdam:
         raise RuntimeError("ArenaAdam steps inside the fused update (por_residual_update / update)")
 
     def state_dict(self):
+        self._agent.flush()
         ms, vs = self._moments()
         state = {}
         if self.step_count > 0:
@@ -58,6 +59,7 @@ class ArenaAdam:
         return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
+        self._agent.flush()
         ms, vs = self._moments()
         steps = set()
         with torch.no_grad():
@@ -140,6 +142,7 @@ class IqlAgentBase(nn.Module):
 
     def _apply(self, fn, recurse=True):
         # .to()/.cuda()/.cpu(): move the flat tensors, then re-create the parameter views
+        self.flush()
         probe = fn(torch.empty(0, dtype=torch.float32, device=self._engine.device))
         if probe.dtype != torch.float32:
             raise RuntimeError("porl_amd agents are fp32 only")
@@ -162,7 +165,24 @@ class IqlAgentBase(nn.Module):
             adam_eps=v_opt.param_groups[0]["eps"])
 
     def _full_update(self, obs, next_obs, rew, term, pol_target, v_opt, p_opt, sched, replay=None, batch=None):
+        """One update = value phase (load, forward, backward, [exchange], Adam + target EMA) then policy phase
+        (second twin forward, weights, NLL, backward, [exchange], Adam), reference por.py:81-110.
+
+        async_losses=False (the reference's behaviour, losses returned as floats): everything on the current stream.
+        async_losses=True: PIPELINED — the policy phase of update t is issued on the engine's side stream and the
+        call returns; update t+1's value phase then runs beside it on the caller's stream.  The only data the two
+        share are the value parameters (policy phase t reads the vf of update t), so two events order
+        value Adam(t) -> policy phase(t) -> value Adam(t+1); minibatch staging is double-buffered in the engine.
+        Same arithmetic, same results; `flush()` (called by everything that reads the agent) joins the streams.
+        With a data-parallel group the two gradient exchanges ride on their phase's stream, so the policy-group
+        all-reduce and most of the value-group one overlap with the other phase's kernels."""
         eng, ex = self._engine, self._exchange
+        world = ex.world_size
+        pipelined = self.async_losses
+        if not pipelined:
+            eng.join()
+        eng._ensure_bound()
+        eng.set_mode((IqlEngine.MODE_TWO_SLOTS if pipelined else 0) | (IqlEngine.MODE_FOLD_COMBINE if world == 1 else 0))
         if replay is not None:
             B = eng.load_batch_sampled(replay.rows, batch, replay.seed, replay.draws, replay.act_dim,
                                        self._engine.cfg.weight_mode == 1)
@@ -172,50 +192,58 @@ class IqlAgentBase(nn.Module):
         v_opt.step_count += 1
         p_opt.step_count += 1
         hp = self._hyper(B, v_opt, p_opt)
-        if ex.world_size == 1:
+        if world == 1 and not pipelined:
             eng.step(hp)
-        else:
-            # replay sharded across ranks: each rank's gradients carry 1/B_global, so SUM == global mean
-            eng.value_backward(hp)
-            work = ex.allreduce_sum_async(eng.grads_vf)
-            self.flush()                       # policy Adam of the PREVIOUS update, if its exchange was deferred
-            if pol_target is not None or replay is not None:
-                eng.policy_prefetch()          # policy MLP forward needs no value net: runs under the all-reduce
-            if work is not None:
-                work.wait()
-            eng.value_apply(hp)
-            eng.policy_backward(hp)
-            if self.async_losses:
-                # Nothing reads the policy before the next update's policy phase: start its gradient exchange
-                # now and let it run under the next update's value phase (sampling, 2 forward layers, backward,
-                # Adam: ~200 us on one MI355X); the Adam step is applied right before it is needed (flush()).
-                # Loss statistics stay per-rank shares in this mode.
-                self._deferred = (ex.allreduce_sum_async(eng.grads_pol), hp)
-            else:
-                ex.allreduce_sum_(eng.grads_pol)
+            sched.step()
+            return self._losses()
+        # ---- value phase (current stream) -----------------------------------------------------------------------
+        # replay sharded across ranks: each rank's gradients carry 1/B_global, so SUM == global mean
+        eng.value_backward(hp)
+        if world > 1:
+            ex.allreduce_sum_(eng.grads_vf)
+        eng.join()                             # policy phase of the PREVIOUS update has read the old value nets
+        eng.value_apply(hp)
+        # ---- policy phase -------------------------------------------------------------------------------------------
+        if pipelined:
+            main, side = torch.cuda.current_stream(eng.device), eng.side_stream()
+            k = (v_opt.step_count & 1) * 2
+            ev_v, ev_p = eng.event(k), eng.event(k + 1)
+            ev_v.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_v)
+                eng.policy_backward(hp)
+                if world > 1:
+                    ex.allreduce_sum_(eng.grads_pol)      # loss statistics stay per-rank shares in this mode
                 eng.policy_apply(hp)
-                ex.allreduce_stats_(eng.stats)
+                ev_p.record(side)
+            eng._policy_done = ev_p
+        else:
+            eng.policy_backward(hp)
+            ex.allreduce_sum_(eng.grads_pol)
+            eng.policy_apply(hp)
+            ex.allreduce_stats_(eng.stats)
         sched.step()
         return self._losses()
 
-    _deferred = None
-
     def flush(self):
-        """Complete a deferred policy step (data-parallel + async_losses mode); a no-op otherwise.  Called
-        automatically before the policy is read (next update, state_dict, forward)."""
-        if self._deferred is not None:
-            work, hp = self._deferred
-            self._deferred = None
-            if work is not None:
-                work.wait()
-            self._engine.policy_apply(hp)
+        """Join an outstanding policy phase (pipelined mode) into the current stream; a no-op otherwise.  Called by
+        everything that reads or writes the agent's state: state_dict / load_state_dict, the optimizers' state,
+        module forwards, vf_update, .to()."""
+        self._engine.join()
 
     def state_dict(self, *args, **kwargs):
         self.flush()
         return super().state_dict(*args, **kwargs)
 
+    def load_state_dict(self, *args, **kwargs):
+        self.flush()
+        return super().load_state_dict(*args, **kwargs)
+
     def _value_update(self, obs, next_obs, rew, term, v_opt):
         eng, ex = self._engine, self._exchange
+        eng.join()
+        eng._ensure_bound()
+        eng.set_mode(IqlEngine.MODE_FOLD_COMBINE if ex.world_size == 1 else 0)
         B = eng.load_batch(obs, next_obs, rew, term, None)
         v_opt.step_count += 1
         hp = self._hyper(B, v_opt, v_opt)

@@ -254,7 +254,7 @@ class FasterNet(nn.Module):
                 raise RuntimeError(f"drop_scale: expected {(len(self._drop_probs), b)}, got {tuple(drop_scale.shape)}")
         out = torch.empty(b, self.num_classes, dtype=torch.float32, device=self._device)
         N.check(self._lib.porl_enc_forward(self._h, N.ptr(x), x.stride(0), b, int(self.training), N.ptr(drop_scale),
-                                           N.ptr(out), out.stride(0), N.current_stream_ptr()), "porl_enc_forward")
+                                           N.ptr(out), out.stride(0), N.current_stream_ptr(self._device)), "porl_enc_forward")
         if self.training:
             torch._foreach_add_(self._nbt, 1)
         return out

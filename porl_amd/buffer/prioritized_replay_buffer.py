@@ -84,7 +84,7 @@ class PrioritizedReplayBuffer:
     def _update(self, tree_idx, td_errors):
         n = tree_idx.numel()
         N.check(N.lib().porl_per_update(N.ptr(self.tree), self.capacity, N.ptr(tree_idx), N.ptr(td_errors), n, self.epsilon,
-                                        self.alpha, N.ptr(self._stamp), N.current_stream_ptr()), "porl_per_update")
+                                        self.alpha, N.ptr(self._stamp), N.current_stream_ptr(self.device)), "porl_per_update")
 
     # -- reference API ---------------------------------------------------------------------------------
     def total_priority(self):
@@ -103,7 +103,7 @@ class PrioritizedReplayBuffer:
         prio = torch.empty(2 * batch_size, dtype=torch.float64, device=self.device)
         w = torch.empty(batch_size, dtype=torch.float32, device=self.device)
         N.check(N.lib().porl_per_sample(N.ptr(self.tree), self.capacity, N.ptr(u), batch_size, self.n_entries, float(self.beta),
-                                        N.ptr(idxs), N.ptr(prio), N.ptr(w), N.current_stream_ptr()), "porl_per_sample")
+                                        N.ptr(idxs), N.ptr(prio), N.ptr(w), N.current_stream_ptr(self.device)), "porl_per_sample")
         slots = idxs - (self.capacity - 1)
         st = self._store
         states = E.gather_rows(st["states"], slots).view(batch_size, *self.state_shape)

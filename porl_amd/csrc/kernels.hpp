@@ -213,79 +213,171 @@ __global__ __launch_bounds__(256) void policy_nll_kernel(const PolicyNllArgs a) 
 
 
 // ---------------------------------------------------------------------------------------------------
-// torch.optim.Adam (single-tensor arithmetic, SURVEY.md §8 a2.3) over a flat parameter group, with the
-// Polyak target update (util/util.py:54-56) fused in:  28 B/param (+8 B/param with the target).
-//   step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) are host doubles rounded to fp32.
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                        float* __restrict__ m, float* __restrict__ v,
-                                                        float* __restrict__ tgt, long n4, float omb1,
-                                                        float beta2, float omb2, float eps, float step_size,
-                                                        float bc2_sqrt, float ema_beta, float omeb) {
-  float4* p4 = reinterpret_cast<float4*>(p);
-  const float4* g4 = reinterpret_cast<const float4*>(g);
-  float4* m4 = reinterpret_cast<float4*>(m);
-  float4* v4 = reinterpret_cast<float4*>(v);
-  float4* t4 = reinterpret_cast<float4*>(tgt);
-  // omb1 = 1-beta1, omb2 = 1-beta2, omeb = 1-ema_beta are host doubles rounded once, like torch's scalars
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    float4 pp = p4[i];
-    const float4 gg = g4[i];
-    float4 mm = m4[i], vv = v4[i];
-#define PORL_ADAM1(c)                                                     \
-    mm.c = mm.c + omb1 * (gg.c - mm.c);                                   \
-    vv.c = vv.c * beta2 + omb2 * gg.c * gg.c;                             \
-    pp.c = pp.c - step_size * (mm.c / (sqrtf(vv.c) / bc2_sqrt + eps));
-    PORL_ADAM1(x) PORL_ADAM1(y) PORL_ADAM1(z) PORL_ADAM1(w)
-#undef PORL_ADAM1
-    p4[i] = pp; m4[i] = mm; v4[i] = vv;
-    if (tgt) {
-      float4 tt = t4[i];
-      tt.x = tt.x * omeb + ema_beta * pp.x; tt.y = tt.y * omeb + ema_beta * pp.y;
-      tt.z = tt.z * omeb + ema_beta * pp.z; tt.w = tt.w * omeb + ema_beta * pp.w;
-      t4[i] = tt;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// split-K combine for several outputs in one launch: out = act(sum_s slab_s + bias)
+// split-K / per-block-partial combine for several outputs: out = act(scale * sum_s slab_s + bias)
 // ---------------------------------------------------------------------------------------------------
 struct ReduceJob {
   float* out; const float* slab; const float* bias;
   long n; long stride; int nslab; int ncols; int act;
   int op;          // 0: sum of the slabs, 1: minimum
   float scale;     // applied to the sum (1 = none)
+  long adam_off;   // fused into the Adam launch only: float offset of out[0] inside the parameter group, or -1
 };
-struct ReduceArgs { int njobs; ReduceJob job[12]; };
+constexpr int MAX_REDUCE_JOBS = 12;
+struct ReduceArgs { int njobs; ReduceJob job[MAX_REDUCE_JOBS]; };
 
-// block = 32 outputs x 8 slab lanes: lane ty adds slabs ty, ty+8, ... (independent loads in flight), then the
-// 8 partial sums are combined in a fixed order through LDS — latency is nslab/8 loads deep, not nslab.
+// One 32-output chunk of a reduce job by a 256-thread block: lane ty adds slabs ty, ty+8, ... (independent loads in
+// flight), then the 8 partial sums are combined in a fixed order through LDS — latency is nslab/8 loads deep, not
+// nslab.  Returns the combined value in the threads with ty == 0 (valid when i < j.n).
+__device__ __forceinline__ float reduce_chunk(const ReduceJob& j, long i0, float (*sh)[33]) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long i = i0 + tx;
+  float s = j.op ? INFINITY : 0.f;
+  if (i < j.n)
+    for (int k = ty; k < j.nslab; k += 8) {
+      const float x = j.slab[(long)k * j.stride + i];
+      s = j.op ? fminf(s, x) : s + x;
+    }
+  sh[ty][tx] = s;
+  __syncthreads();
+  float t = 0.f;
+  if (ty == 0 && i < j.n) {
+    t = sh[0][tx];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t = j.op ? fminf(t, sh[q][tx]) : t + sh[q][tx];
+    t *= j.scale;
+    if (j.bias) t += j.bias[i % j.ncols];
+    if (j.act == 1) t = fmaxf(t, 0.f);
+    else if (j.act == 2) t = tanhf(t);
+  }
+  __syncthreads();
+  return t;
+}
+
 __global__ __launch_bounds__(256) void multi_reduce_kernel(const ReduceArgs a) {
   __shared__ float sh[8][33];
   const ReduceJob& j = a.job[blockIdx.y];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (long i0 = (long)blockIdx.x * 32; i0 < j.n; i0 += (long)gridDim.x * 32) {
-    const long i = i0 + tx;
-    float s = j.op ? INFINITY : 0.f;
-    if (i < j.n)
-      for (int k = ty; k < j.nslab; k += 8) {
-        const float x = j.slab[(long)k * j.stride + i];
-        s = j.op ? fminf(s, x) : s + x;
-      }
-    sh[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0 && i < j.n) {
-      float t = sh[0][tx];
+    const float t = reduce_chunk(j, i0, sh);
+    if (ty == 0 && i0 + tx < j.n) j.out[i0 + tx] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// torch.optim.Adam (single-tensor arithmetic, SURVEY.md §8 a2.3) over a flat parameter group, with the
+// Polyak target update (util/util.py:54-56) fused in:  28 B/param (+8 B/param with the target).
+//   step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) are host doubles rounded to fp32.
+// The same launch can also FINISH the gradient: split-K slabs and per-block partial sums that the backward kernels
+// left behind are combined here instead of in a launch of their own —
+//   * short regions (nslab <= ADAM_SWEEP_SLABS, e.g. the split-K slabs of the (H, S) input-layer weights) inside the
+//     float4 sweep: the thread that owns a float4 sums its slabs first (multi_reduce's order: 8 interleaved partial
+//     sums, combined in index order, so the result is bit-identical to the separate combine launch);
+//   * long ones (per-block partials of the loss heads: B/16 .. B/4 of them) by extra blocks that run reduce_chunk and
+//     then apply Adam to their 32 outputs; jobs with adam_off < 0 (the loss statistics) just store.
+// The combined gradient is also written to g, so the gradient buffer is complete after the launch.
+// ---------------------------------------------------------------------------------------------------
+struct AdamScalars { float omb1, beta2, omb2, eps, step_size, bc2_sqrt, ema_beta, omeb; };
+constexpr int ADAM_SWEEP_SLABS = 16;
+constexpr int MAX_ADAM_REGIONS = 8;
+struct AdamRegion { long lo, hi; const float* slab; long stride; int nslab; };   // floats [lo, hi), multiples of 4;
+                                                                                // slab indexed from lo
+struct AdamArgs {
+  float* p; float* g; float* m; float* v; float* tgt;
+  long n4;              // float4 in the group
+  long span4;           // float4 per sweep block (contiguous)
+  int sweep_blocks;     // blocks [0, sweep_blocks) sweep, the rest are reduce blocks
+  AdamScalars s;
+  int nregions; AdamRegion region[MAX_ADAM_REGIONS];
+  int nskip; long skip_lo[MAX_REDUCE_JOBS], skip_hi[MAX_REDUCE_JOBS];   // float ranges owned by reduce blocks
+  int job_block0[MAX_REDUCE_JOBS + 1];                                   // first reduce block of job j (prefix sums)
+  ReduceArgs r;
+};
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamScalars& s) {
+  m = m + s.omb1 * (g - m);
+  v = v * s.beta2 + s.omb2 * g * g;
+  p = p - s.step_size * (m / (sqrtf(v) / s.bc2_sqrt + s.eps));
+}
+
+__global__ __launch_bounds__(256) void adam_ema_kernel(const AdamArgs a) {
+  __shared__ float sh[8][33];
+  const AdamScalars s = a.s;
+  if ((int)blockIdx.x >= a.sweep_blocks) {
+    // ---- reduce block: one 32-output chunk of one job, then Adam on those outputs --------------------------
+    const int rb = blockIdx.x - a.sweep_blocks;
+    int ji = 0;
 #pragma unroll
-      for (int q = 1; q < 8; ++q) t = j.op ? fminf(t, sh[q][tx]) : t + sh[q][tx];
-      t *= j.scale;
-      if (j.bias) t += j.bias[i % j.ncols];
-      if (j.act == 1) t = fmaxf(t, 0.f);
-      else if (j.act == 2) t = tanhf(t);
-      j.out[i] = t;
+    for (int q = 1; q < MAX_REDUCE_JOBS; ++q)
+      if (q < a.r.njobs && rb >= a.job_block0[q]) ji = q;
+    const ReduceJob& j = a.r.job[ji];
+    const long i0 = (long)(rb - a.job_block0[ji]) * 32;
+    const float t = reduce_chunk(j, i0, sh);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (ty == 0 && i0 + tx < j.n) {
+      j.out[i0 + tx] = t;
+      if (j.adam_off >= 0) {
+        const long e = j.adam_off + i0 + tx;
+        float pp = a.p[e], mm = a.m[e], vv = a.v[e];
+        adam1(pp, t, mm, vv, s);
+        a.p[e] = pp; a.m[e] = mm; a.v[e] = vv;
+        if (a.tgt) a.tgt[e] = a.tgt[e] * s.omeb + s.ema_beta * pp;
+      }
     }
-    __syncthreads();
+    return;
+  }
+  // ---- sweep block: a contiguous span of float4 ----------------------------------------------------------------
+  float4* p4 = reinterpret_cast<float4*>(a.p);
+  float4* g4 = reinterpret_cast<float4*>(a.g);
+  float4* m4 = reinterpret_cast<float4*>(a.m);
+  float4* v4 = reinterpret_cast<float4*>(a.v);
+  float4* t4 = reinterpret_cast<float4*>(a.tgt);
+  const long lo4 = (long)blockIdx.x * a.span4, hi4 = min(a.n4, lo4 + a.span4);
+  // block-uniform: does this span touch a slab region or a range owned by reduce blocks at all?
+  bool special = false;
+  for (int q = 0; q < a.nregions; ++q) special = special || (lo4 * 4 < a.region[q].hi && hi4 * 4 > a.region[q].lo);
+  for (int q = 0; q < a.nskip; ++q) special = special || (lo4 * 4 < a.skip_hi[q] && hi4 * 4 > a.skip_lo[q]);
+  for (long i = lo4 + threadIdx.x; i < hi4; i += 256) {
+    float4 gg;
+    bool have_g = false;
+    if (special) {
+      const long e = i * 4;
+      bool skip = false;
+      for (int q = 0; q < a.nskip; ++q) skip = skip || (e >= a.skip_lo[q] && e < a.skip_hi[q]);
+      if (skip) continue;
+      for (int q = 0; q < a.nregions; ++q) {
+        const AdamRegion& R = a.region[q];
+        if (e >= R.lo && e < R.hi) {
+          // 8 interleaved partial sums (slab k goes to partial k & 7), combined in index order: multi_reduce's order
+          float4 part[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) part[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float* base = R.slab + (e - R.lo);
+#pragma unroll
+          for (int k = 0; k < ADAM_SWEEP_SLABS; ++k)
+            if (k < R.nslab) {
+              const float4 x = *reinterpret_cast<const float4*>(base + (long)k * R.stride);
+              part[k & 7].x += x.x; part[k & 7].y += x.y; part[k & 7].z += x.z; part[k & 7].w += x.w;
+            }
+          gg = part[0];
+#pragma unroll
+          for (int u = 1; u < 8; ++u) { gg.x += part[u].x; gg.y += part[u].y; gg.z += part[u].z; gg.w += part[u].w; }
+          g4[i] = gg;
+          have_g = true;
+        }
+      }
+    }
+    if (!have_g) gg = g4[i];
+    float4 pp = p4[i];
+    float4 mm = m4[i], vv = v4[i];
+    adam1(pp.x, gg.x, mm.x, vv.x, s); adam1(pp.y, gg.y, mm.y, vv.y, s);
+    adam1(pp.z, gg.z, mm.z, vv.z, s); adam1(pp.w, gg.w, mm.w, vv.w, s);
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    if (a.tgt) {
+      float4 tt = t4[i];
+      tt.x = tt.x * s.omeb + s.ema_beta * pp.x; tt.y = tt.y * s.omeb + s.ema_beta * pp.y;
+      tt.z = tt.z * s.omeb + s.ema_beta * pp.z; tt.w = tt.w * s.omeb + s.ema_beta * pp.w;
+      t4[i] = tt;
+    }
   }
 }
 
@@ -351,14 +443,17 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   return x;
 }
 
-__device__ __forceinline__ int64_t feistel_index(int64_t n, int i, uint64_t seed, uint64_t step, int hb) {
+__device__ __forceinline__ int64_t feistel_index(int64_t n, int64_t i, uint64_t seed, uint64_t step, int hb) {
   const uint32_t mask = (1u << hb) - 1u;
   uint32_t keys[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     keys[r] = mix32((uint32_t)(seed >> (r & 1 ? 32 : 0)) ^ mix32((uint32_t)step * 4u + r) ^ (uint32_t)(step >> 30));
+  // Cycle walking: apply the bijection of [0, 4^hb) until the image lands in [0, n).  The walk follows the cycle
+  // of i, which contains i < n itself, so it always ends (the domain is < 4n: fewer than 4 rounds on average) and
+  // the restriction to [0, n) is again a bijection — every position maps to a distinct row.
   uint64_t x = (uint64_t)i;
-  for (int iter = 0; iter < 64; ++iter) {
+  do {
     uint32_t L = (uint32_t)(x >> hb) & mask, R = (uint32_t)x & mask;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -367,9 +462,7 @@ __device__ __forceinline__ int64_t feistel_index(int64_t n, int i, uint64_t seed
       L = R; R = t;
     }
     x = ((uint64_t)L << hb) | R;
-    if ((int64_t)x < n) break;
-  }
-  if ((int64_t)x >= n) x = (uint64_t)i;
+  } while ((int64_t)x >= n);
   return (int64_t)x;
 }
 
@@ -408,7 +501,7 @@ __global__ void sample_indices_kernel(int64_t n, int batch, uint64_t seed, uint6
                                       int64_t base, int64_t first, int64_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= batch) return;
-  out[i] = base + feistel_index(n, first + i, seed, step, hb);
+  out[i] = base + feistel_index(n, first + (int64_t)i, seed, step, hb);
 }
 
 // ---------------------------------------------------------------------------------------------------

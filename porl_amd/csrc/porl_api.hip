@@ -45,6 +45,24 @@ thread_local std::string g_err;
     if (_r != 0) return _r;     \
   } while (0)
 
+// Every entry point launches on the device that owns its buffers, whatever the calling thread's current device is:
+// handles remember the ordinal of their workspace at bind time, stateless entry points look it up from a pointer.
+struct DevGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DevGuard(int dev) {
+    if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
+  DevGuard(const DevGuard&) = delete;
+  DevGuard& operator=(const DevGuard&) = delete;
+};
+int device_of(const void* p) {
+  hipPointerAttribute_t a;
+  if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return a.type == hipMemoryTypeDevice ? a.device : -1;
+}
+
 // ---- optional per-launch timing with HIP events (bench.py's roofline leg) ---------------------------
 struct ProfRec { int label; hipEvent_t e0, e1; double flops, bytes; };
 struct ProfState {
@@ -64,11 +82,13 @@ struct ProfState {
   }
 } g_prof;
 
+const char* g_phase = "";     // prefix of the profile labels: which launch of the update step this is (profiling only)
+
 struct ProfScope {
   bool active; ProfRec r; hipStream_t s;
   ProfScope(const std::string& label, hipStream_t st, double flops, double bytes) : active(g_prof.on), s(st) {
     if (!active) return;
-    r.label = g_prof.label_id(label); r.flops = flops; r.bytes = bytes;
+    r.label = g_prof.label_id(std::string(g_phase) + label); r.flops = flops; r.bytes = bytes;
     r.e0 = g_prof.get(); r.e1 = g_prof.get();
     (void)hipEventRecord(r.e0, s);
   }
@@ -128,12 +148,16 @@ void layout_mlp(MlpLayout& m, std::vector<TensorInfo>& v, int64_t& cur, int in, 
 }
 
 struct Workspace {
-  int64_t xs, xn, xt, rew, term;
+  // xs / xt / target_v exist twice ("batch slots"): with PORL_IQL_MODE_TWO_SLOTS every load flips the slot, so the
+  // policy phase of update t (on its own stream) can still read its minibatch while update t+1 is being loaded
+  int64_t xs_slot[2], xt_slot[2], target_v_slot[2];
+  int64_t xn, rew, term;
   int64_t act_v[2][PORL_MAX_HIDDEN], act_t[2][2], act_p[PORL_MAX_HIDDEN];
   int64_t dz_v[2][2], dz_p[2];
   int64_t hp_t[2], hp_v[2];
-  int64_t target_v, dv[2], dmu;
-  int64_t slab_mean, slab_a, slab_b;
+  int64_t act_q[2][2], hp_q[2];      // policy phase only: scratch of the second twin forward and its head partials
+  int64_t dv[2], dmu;
+  int64_t slab_mean, slab_a, slab_b, slab_pa;   // slab_pa: the policy phase's own split-K slabs for dW0
   int64_t part_loss, part_min, part_dls;
   int64_t xhat_v[2][PORL_MAX_HIDDEN], rstd_v[2][PORL_MAX_HIDDEN];   // LayerNorm only
   int64_t ln_dg[2], ln_db[2], ln_dh[2];
@@ -150,6 +174,11 @@ struct porl_iql {
   std::vector<TensorInfo> t_vf, t_pol;
   porl_iql_buffers buf{};
   bool bound = false;
+  int device = -1;                  // ordinal of the device that owns the bound buffers
+  int mode = 0;                     // PORL_IQL_MODE_* bits
+  int slot = 0;                     // batch slot of the most recent load
+  ReduceArgs fin_v{}, fin_p{};      // PORL_IQL_MODE_FOLD_COMBINE: combines left pending by *_backward for *_apply
+  bool fin_v_pending = false, fin_p_pending = false;
   int batch = 0;
   bool have_pol_target = false;
   bool pol_prefetched = false;      // porl_iql_policy_prefetch ran for the loaded batch: policy forward is done
@@ -225,6 +254,7 @@ int launch_reduce(ReduceArgs& r, hipStream_t s) {
   long maxn = 0;
   for (int i = 0; i < r.njobs; ++i) maxn = std::max(maxn, r.job[i].n);
   dim3 grid((unsigned)std::min<long>((maxn + 31) / 32, 2048), r.njobs);
+  ProfScope ps("multi_reduce_kernel", s, 0.0, 0.0);
   hipLaunchKernelGGL(multi_reduce_kernel, grid, dim3(256), 0, s, r);
   PORL_HIP(hipGetLastError());
   return 0;
@@ -234,7 +264,7 @@ void add_reduce(ReduceArgs& r, float* out, const float* slab, long n, long strid
                 float scale = 1.f) {
   ReduceJob& j = r.job[r.njobs++];
   j.out = out; j.slab = slab; j.bias = nullptr; j.n = n; j.stride = stride; j.nslab = nslab; j.ncols = 1; j.act = 0;
-  j.op = op; j.scale = scale;
+  j.op = op; j.scale = scale; j.adam_off = -1;
 }
 
 int check_ready(const porl_iql* h, bool need_batch) {
@@ -325,22 +355,27 @@ int porl_iql_create(const porl_iql_cfg* c, porl_iql** out) {
   int64_t o = 0;
   auto take = [&](int64_t n) { int64_t r = o; o += ru4(n); return r; };
   const int64_t BH = (int64_t)B * h->Hp;
-  w.xs = take((int64_t)B * h->Sp); w.xn = take((int64_t)B * h->Sp); w.xt = take((int64_t)B * h->Dp);
+  for (int k = 0; k < 2; ++k) {
+    w.xs_slot[k] = take((int64_t)B * h->Sp); w.xt_slot[k] = take((int64_t)B * h->Dp); w.target_v_slot[k] = take(B);
+  }
+  w.xn = take((int64_t)B * h->Sp);
   w.rew = take(B); w.term = take(B);
   for (int i = 0; i < 2; ++i) {
     for (int l = 0; l < L; ++l) w.act_v[i][l] = take(BH);
     w.act_t[i][0] = take(BH); w.act_t[i][1] = take(BH);
+    w.act_q[i][0] = take(BH); w.act_q[i][1] = take(BH);
+    w.hp_q[i] = take((int64_t)h->parts_max * B);
     w.dz_v[i][0] = take(BH); w.dz_v[i][1] = take(BH);
     w.hp_t[i] = take((int64_t)h->parts_max * B); w.hp_v[i] = take((int64_t)h->parts_max * B);
     w.dv[i] = take(B);
   }
   for (int l = 0; l < L; ++l) w.act_p[l] = take(BH);
   w.dz_p[0] = take(BH); w.dz_p[1] = take(BH);
-  w.target_v = take(B);
   w.dmu = take((int64_t)B * h->Dp);
   w.slab_mean = take((int64_t)SK_MAX * B * h->Dp);
   w.slab_a = take((int64_t)SK_MAX * 2 * ((int64_t)H * S + 2 * H + 8));
   w.slab_b = take((int64_t)SK_MAX * ((int64_t)D * H + D + 8));
+  w.slab_pa = take((int64_t)SK_MAX * ((int64_t)H * S + 2 * H + 8));
   const int nblk = cdiv(B, NLL_ROWS_PER_BLOCK);
   w.part_loss = take(nblk); w.part_min = take(nblk); w.part_dls = take((int64_t)nblk * D);
   for (int i = 0; i < 2; ++i) { w.head_part[i] = take((int64_t)cdiv(B, HEAD_ROWS_PER_BLOCK) * H); w.head_db[i] = take(cdiv(B, HEAD_ROWS_PER_BLOCK)); }
@@ -384,6 +419,7 @@ int porl_iql_bind(porl_iql* h, const porl_iql_buffers* b) {
   }
   h->buf = *b;
   h->bound = true;
+  h->device = device_of(b->workspace);
   h->batch = 0;
   return PORL_OK;
 }
@@ -391,21 +427,22 @@ int porl_iql_bind(porl_iql* h, const porl_iql_buffers* b) {
 int porl_iql_load_batch(porl_iql* h, int32_t batch, const float* obs, int64_t obs_rs, const float* next_obs,
                         int64_t next_rs, const float* rew, int64_t rew_rs, const float* term, int64_t term_rs,
                         const float* pol_target, int64_t pt_rs, void* stream) {
-  PORL_TRY(check_ready(h, false));
+  PORL_TRY(check_ready(h, false)); DevGuard _dg(h->device);
   if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
   if (!obs || !next_obs || !rew || !term) PORL_FAIL(PORL_ERR_INVALID, "null batch tensor");
   float* W = h->buf.workspace;
+  if (h->mode & PORL_IQL_MODE_TWO_SLOTS) h->slot ^= 1;
   PackArgs a{};
   a.rows = batch;
   auto job = [&](const float* src, int64_t rs, float* dst, int cols, int ld) {
     PackJob& j = a.job[a.njobs++];
     j.src = src; j.dst = dst; j.src_row_stride = rs; j.src_col_stride = 1; j.cols = cols; j.ld = ld;
   };
-  job(obs, obs_rs, W + h->ws.xs, h->cfg.obs_dim, h->Sp);
+  job(obs, obs_rs, W + h->ws.xs_slot[h->slot], h->cfg.obs_dim, h->Sp);
   job(next_obs, next_rs, W + h->ws.xn, h->cfg.obs_dim, h->Sp);
   job(rew, rew_rs, W + h->ws.rew, 1, 1);
   job(term, term_rs, W + h->ws.term, 1, 1);
-  if (pol_target) job(pol_target, pt_rs, W + h->ws.xt, h->cfg.pol_out_dim, h->Dp);
+  if (pol_target) job(pol_target, pt_rs, W + h->ws.xt_slot[h->slot], h->cfg.pol_out_dim, h->Dp);
   h->have_pol_target = pol_target != nullptr;
   h->pol_prefetched = false;
   const long n = (long)batch * std::max(h->Sp, h->Dp);
@@ -418,7 +455,7 @@ int porl_iql_load_batch(porl_iql* h, int32_t batch, const float* obs, int64_t ob
 
 // LayerNorm variant of the value backward: dZ of every hidden layer is materialised by the LayerNorm
 // backward kernel (row statistics), gamma/beta/(head) gradients come from its per-block partial sums.
-static int value_backward_ln(porl_iql* h, const porl_iql_hyper* hp, hipStream_t s) {
+static int value_backward_ln(porl_iql* h, const porl_iql_hyper* hp, hipStream_t s, ReduceArgs* defer) {
   (void)hp;
   const int B = h->batch, S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden, Hp = h->Hp;
   float* W = h->buf.workspace;
@@ -455,7 +492,7 @@ static int value_backward_ln(porl_iql* h, const porl_iql_hyper* hp, hipStream_t 
     GemmGroup g{};
     for (int i = 0; i < 2; ++i) {
       const float* dz = W + ws.dz_v[i][1];
-      const float* in = l == 0 ? W + ws.xs : W + ws.act_v[i][l - 1];
+      const float* in = l == 0 ? W + ws.xs_slot[h->slot] : W + ws.act_v[i][l - 1];
       const int ldin = l == 0 ? h->Sp : Hp;
       GemmProb p = make_prob(GEMM_TN, dz, Hp, in, ldin, Gv + h->v[i].w[l], Kin, H, Kin, B);
       p.colsum = Gv + h->v[i].b[l];
@@ -480,7 +517,8 @@ static int value_backward_ln(porl_iql* h, const porl_iql_hyper* hp, hipStream_t 
       }
     }
     PORL_TRY(launch_group(g, tile, s));
-    PORL_TRY(launch_reduce(red, s));
+    if (l == 0 && defer) *defer = red;       // only the last combine can wait for the Adam launch: the LayerNorm
+    else PORL_TRY(launch_reduce(red, s));    // partial buffers are reused layer by layer
   }
   return PORL_OK;
 }
@@ -494,21 +532,27 @@ static int feistel_half_bits(int64_t n_rows) {
 int porl_iql_load_batch_sampled(porl_iql* h, int32_t batch, const float* rows, int64_t row_stride, int64_t n_rows,
                                 int32_t act_dim, int32_t target_is_action, uint64_t seed, uint64_t step,
                                 int64_t* idx_out, void* stream) {
-  PORL_TRY(check_ready(h, false));
+  PORL_TRY(check_ready(h, false)); DevGuard _dg(h->device);
   if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
   if (!rows || n_rows < batch || n_rows > (int64_t(1) << 40)) PORL_FAIL(PORL_ERR_INVALID, "need batch <= n_rows");
   const int S = h->cfg.obs_dim, D = h->cfg.pol_out_dim;
   if (row_stride < 2 * (int64_t)S + 2 + act_dim) PORL_FAIL(PORL_ERR_INVALID, "row stride shorter than 2*S+2+A");
   if (target_is_action ? D != act_dim : D != S) PORL_FAIL(PORL_ERR_INVALID, "policy target width mismatch");
   float* W = h->buf.workspace;
+  if (h->mode & PORL_IQL_MODE_TWO_SLOTS) h->slot ^= 1;
   SampledBatchArgs a{};
   a.rows = rows; a.row_stride = (long)row_stride; a.n_rows = n_rows;
   a.batch = batch; a.S = S; a.A = act_dim; a.D = D; a.Sp = h->Sp; a.Dp = h->Dp;
   a.hb = feistel_half_bits(n_rows); a.target_is_action = target_is_action;
   a.seed = seed; a.step = step;
-  a.xs = W + h->ws.xs; a.xn = W + h->ws.xn; a.xt = W + h->ws.xt; a.rew = W + h->ws.rew; a.term = W + h->ws.term;
+  a.xs = W + h->ws.xs_slot[h->slot]; a.xn = W + h->ws.xn; a.xt = W + h->ws.xt_slot[h->slot]; a.rew = W + h->ws.rew; a.term = W + h->ws.term;
   a.idx_out = idx_out;
-  hipLaunchKernelGGL(sampled_batch_kernel, dim3(cdiv(batch, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  {
+    g_phase = "V1.";
+    ProfScope ps("sampled_batch_kernel", (hipStream_t)stream, 0.0, 8.0 * batch * (2 * S + 2 + act_dim));
+    hipLaunchKernelGGL(sampled_batch_kernel, dim3(cdiv(batch, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    g_phase = "";
+  }
   PORL_HIP(hipGetLastError());
   h->batch = batch;
   h->have_pol_target = true;
@@ -516,18 +560,25 @@ int porl_iql_load_batch_sampled(porl_iql* h, int32_t batch, const float* rows, i
   return PORL_OK;
 }
 
+int porl_iql_set_mode(porl_iql* h, int32_t mode) {
+  if (!h) PORL_FAIL(PORL_ERR_INVALID, "null engine");
+  if (mode & ~(PORL_IQL_MODE_TWO_SLOTS | PORL_IQL_MODE_FOLD_COMBINE)) PORL_FAIL(PORL_ERR_INVALID, "unknown mode bits");
+  if (h->fin_v_pending || h->fin_p_pending) PORL_FAIL(PORL_ERR_INVALID, "a backward pass is waiting for its apply call");
+  h->mode = mode;
+  return PORL_OK;
+}
+
 int porl_iql_set_stats(porl_iql* h, float* stats) {
-  PORL_TRY(check_ready(h, false));
+  PORL_TRY(check_ready(h, false)); DevGuard _dg(h->device);
   if (!stats) PORL_FAIL(PORL_ERR_INVALID, "null stats");
   h->buf.stats = stats;
   return PORL_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------
-int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
-  PORL_TRY(check_ready(h, true));
-  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
-  hipStream_t s = (hipStream_t)stream;
+// `defer` (optional): the final combine launch is not issued; its jobs are handed to the caller, who folds them into
+// the Adam launch (porl_iql_step).
+static int value_backward_impl(porl_iql* h, const porl_iql_hyper* hp, hipStream_t s, ReduceArgs* defer) {
   const int B = h->batch, S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden, Hp = h->Hp;
   float* W = h->buf.workspace;
   const Workspace& ws = h->ws;
@@ -546,7 +597,7 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
       const int i = n & 1;
       const float* P = tgt ? Pt : Pv;
       FwdNet& f = nets[n];
-      if (l == 0) { f.in = W + (tgt ? ws.xn : ws.xs); f.ldin = h->Sp; }
+      if (l == 0) { f.in = W + (tgt ? ws.xn : ws.xs_slot[h->slot]); f.ldin = h->Sp; }
       else { f.in = W + (tgt ? ws.act_t[i][(l - 1) & 1] : ws.act_v[i][l - 1]); f.ldin = Hp; }
       f.W = P + h->v[i].w[l]; f.b = P + h->v[i].b[l];
       const bool last = l == L - 1;
@@ -558,8 +609,10 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
         if (!tgt) { f.xhat = W + ws.xhat_v[i][l]; f.rstd = W + ws.rstd_v[i][l]; }
       }
     }
+    g_phase = l == 0 ? "V2.L0fwd:" : "V3.fwd:";
     PORL_TRY(fwd_hidden_layer(h, nets, 4, B, K, l == L - 1, &parts, s));
   }
+  g_phase = "V4.head:";
 
   // -- TD target, expectile loss, dL/dv: with LayerNorm a kernel of its own; otherwise fused into the head
   //    backward below --------------------------------------------------------------------------------------
@@ -571,14 +624,14 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
       a.dv[i] = W + ws.dv[i];
       a.db_out[i] = Gv + h->v[i].b[L];
     }
-    a.rew = W + ws.rew; a.term = W + ws.term; a.target_v = W + ws.target_v; a.stats = h->buf.stats;
+    a.rew = W + ws.rew; a.term = W + ws.term; a.target_v = W + ws.target_v_slot[h->slot]; a.stats = h->buf.stats;
     a.B = B; a.parts = parts; a.tau = hp->tau; a.discount = hp->discount; a.inv_batch = hp->inv_batch;
     hipLaunchKernelGGL(value_loss_kernel, dim3(1), dim3(1024), 0, s, a);
     PORL_HIP(hipGetLastError());
   }
 
   ReduceArgs red{};
-  if (LN) return value_backward_ln(h, hp, s);
+  if (LN) return value_backward_ln(h, hp, s, defer);
   // -- head + last ReLU backward: dZ_{L-1} = dv w_L^T . 1[H_{L-1} > 0], dW_L = dv^T H_{L-1} (partials) -----
   {
     const int nhb = cdiv(B, HEAD_ROWS_PER_BLOCK);
@@ -592,10 +645,11 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
       add_reduce(red, Gv + h->v[i].w[L], W + ws.head_part[i], H, H, nhb);
       add_reduce(red, Gv + h->v[i].b[L], W + ws.head_db[i], 1, 1, nhb);
     }
-    a.rew = W + ws.rew; a.term = W + ws.term; a.target_v = W + ws.target_v; a.part_loss = W + ws.head_loss;
+    a.rew = W + ws.rew; a.term = W + ws.term; a.target_v = W + ws.target_v_slot[h->slot]; a.part_loss = W + ws.head_loss;
     add_reduce(red, h->buf.stats, W + ws.head_loss, 1, 1, nhb, 0, hp->inv_batch);     // stats[0] = v_loss
     a.B = B; a.H = H; a.ld = Hp; a.parts = parts;
     a.tau = hp->tau; a.discount = hp->discount; a.inv_batch = hp->inv_batch;
+    ProfScope ps("relu_head_bwd_kernel", s, 0.0, 16.0 * B * H);
     hipLaunchKernelGGL(relu_head_bwd_kernel, dim3(nhb, 2), dim3(256), 0, s, a);
     PORL_HIP(hipGetLastError());
   }
@@ -604,7 +658,7 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
     GemmGroup g{};
     for (int i = 0; i < 2; ++i) {
       const float* dz = W + ws.dz_v[i][l & 1];
-      const float* in = l == 0 ? W + ws.xs : W + ws.act_v[i][l - 1];
+      const float* in = l == 0 ? W + ws.xs_slot[h->slot] : W + ws.act_v[i][l - 1];
       const int ldin = l == 0 ? h->Sp : Hp;
       GemmProb p = make_prob(GEMM_TN, dz, Hp, in, ldin, Gv + h->v[i].w[l], Kin, H, Kin, B);
       p.colsum = Gv + h->v[i].b[l];
@@ -632,47 +686,102 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
         }
       }
     }
+    g_phase = l == 0 ? "V6.dW0:" : "V5.bwd:";
     PORL_TRY(launch_group(g, tile, s));
   }
-  PORL_TRY(launch_reduce(red, s));
+  g_phase = "V7.combine:";
+  if (defer) *defer = red;
+  else PORL_TRY(launch_reduce(red, s));
+  g_phase = "";
+  return PORL_OK;
+}
+
+int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
+  PORL_TRY(check_ready(h, true)); DevGuard _dg(h->device);
+  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+  const bool fold = (h->mode & PORL_IQL_MODE_FOLD_COMBINE) != 0;
+  h->fin_v = ReduceArgs{};
+  PORL_TRY(value_backward_impl(h, hp, (hipStream_t)stream, fold ? &h->fin_v : nullptr));
+  h->fin_v_pending = fold;
   return PORL_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------
-static int adam_launch(float* p, const float* g, float* m, float* v, float* tgt, int64_t n, double lr, int step,
-                       double b1, double b2, double eps, double ema_beta, hipStream_t s) {
+// Adam(+EMA) over one flat group.  `fin` (optional): combine jobs that the backward pass left pending; those whose
+// output lies inside the gradient buffer `g` are folded into this launch (short slab lists inside the float4 sweep,
+// long ones as extra reduce+Adam blocks), the others (loss statistics) ride along as plain reduce blocks.
+static int adam_launch(float* p, float* g, float* m, float* v, float* tgt, int64_t n, double lr, int step,
+                       double b1, double b2, double eps, double ema_beta, hipStream_t s, const ReduceArgs* fin = nullptr) {
   if (n % 4) PORL_FAIL(PORL_ERR_INVALID, "adam range must be a multiple of 4 floats");
   if (step < 1) PORL_FAIL(PORL_ERR_INVALID, "adam step must be >= 1");
+  AdamArgs a{};
+  a.p = p; a.g = g; a.m = m; a.v = v; a.tgt = tgt;
   // torch._single_tensor_adam: python doubles, rounded to fp32 where they meet tensors
   const double bc1 = 1.0 - std::pow(b1, (double)step);
   const double bc2 = 1.0 - std::pow(b2, (double)step);
-  const float step_size = (float)(lr / bc1);
-  const float bc2_sqrt = (float)std::sqrt(bc2);
-  const float omb1 = (float)(1.0 - b1), omb2 = (float)(1.0 - b2);
-  const float omeb = (float)(1.0 - ema_beta);
-  const long n4 = n / 4;
-  const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 2048);
-  ProfScope ps("adam_ema_kernel", s, 0.0, (double)n * (tgt ? 36.0 : 28.0));
-  hipLaunchKernelGGL(adam_ema_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, tgt, n4, omb1, (float)b2, omb2,
-                     (float)eps, step_size, bc2_sqrt, (float)ema_beta, omeb);
+  a.s.step_size = (float)(lr / bc1);
+  a.s.bc2_sqrt = (float)std::sqrt(bc2);
+  a.s.omb1 = (float)(1.0 - b1); a.s.beta2 = (float)b2; a.s.omb2 = (float)(1.0 - b2);
+  a.s.eps = (float)eps; a.s.ema_beta = (float)ema_beta; a.s.omeb = (float)(1.0 - ema_beta);
+  a.n4 = n / 4;
+  a.sweep_blocks = (int)std::min<long>((a.n4 + 255) / 256, 2048);
+  a.span4 = (a.n4 + a.sweep_blocks - 1) / a.sweep_blocks;
+  int reduce_blocks = 0;
+  double extra_bytes = 0.0;
+  if (fin) {
+    for (int q = 0; q < fin->njobs; ++q) {
+      ReduceJob j = fin->job[q];
+      const bool inside = j.out >= g && j.out + j.n <= g + n;
+      const long off = inside ? (long)(j.out - g) : -1;
+      extra_bytes += 4.0 * (double)j.n * j.nslab;
+      const bool plain = j.op == 0 && j.scale == 1.f && !j.bias && j.act == 0;
+      if (inside && plain && j.nslab <= ADAM_SWEEP_SLABS && off % 4 == 0 && j.n % 4 == 0 && j.stride % 4 == 0 &&
+          aligned16(j.slab) && a.nregions < MAX_ADAM_REGIONS) {
+        AdamRegion& R = a.region[a.nregions++];
+        R.lo = off; R.hi = off + j.n; R.slab = j.slab; R.stride = j.stride; R.nslab = j.nslab;
+        continue;
+      }
+      if (inside) {
+        if (off % 4) PORL_FAIL(PORL_ERR_INVALID, "gradient tensors start on 16-byte boundaries");
+        j.adam_off = off;
+        a.skip_lo[a.nskip] = off; a.skip_hi[a.nskip] = ru4(off + j.n); ++a.nskip;
+      } else {
+        j.adam_off = -1;
+      }
+      a.job_block0[a.r.njobs] = reduce_blocks;
+      a.r.job[a.r.njobs++] = j;
+      reduce_blocks += (int)((j.n + 31) / 32);
+    }
+    a.job_block0[a.r.njobs] = reduce_blocks;
+  }
+  ProfScope ps("adam_ema_kernel", s, 0.0, (double)n * (tgt ? 36.0 : 28.0) + extra_bytes);
+  hipLaunchKernelGGL(adam_ema_kernel, dim3(a.sweep_blocks + reduce_blocks), dim3(256), 0, s, a);
   PORL_HIP(hipGetLastError());
   return PORL_OK;
 }
 
 int porl_iql_value_apply(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
-  PORL_TRY(check_ready(h, false));
+  PORL_TRY(check_ready(h, false)); DevGuard _dg(h->device);
   if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
-  return adam_launch(h->buf.params_vf, h->buf.grads_vf, h->buf.adam_m_vf, h->buf.adam_v_vf, h->buf.params_tgt,
-                     h->n_vf, hp->value_lr, hp->value_step, hp->adam_beta1, hp->adam_beta2, hp->adam_eps,
-                     hp->ema_beta, (hipStream_t)stream);
+  g_phase = "V8.";
+  const int rc = adam_launch(h->buf.params_vf, h->buf.grads_vf, h->buf.adam_m_vf, h->buf.adam_v_vf, h->buf.params_tgt,
+                             h->n_vf, hp->value_lr, hp->value_step, hp->adam_beta1, hp->adam_beta2, hp->adam_eps,
+                             hp->ema_beta, (hipStream_t)stream, h->fin_v_pending ? &h->fin_v : nullptr);
+  g_phase = "";
+  h->fin_v_pending = false;
+  return rc;
 }
 
 int porl_iql_policy_apply(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
-  PORL_TRY(check_ready(h, false));
+  PORL_TRY(check_ready(h, false)); DevGuard _dg(h->device);
   if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
-  return adam_launch(h->buf.params_pol, h->buf.grads_pol, h->buf.adam_m_pol, h->buf.adam_v_pol, nullptr, h->n_pol,
-                     hp->policy_lr, hp->policy_step, hp->adam_beta1, hp->adam_beta2, hp->adam_eps, 0.0,
-                     (hipStream_t)stream);
+  g_phase = "P9.";
+  const int rc = adam_launch(h->buf.params_pol, h->buf.grads_pol, h->buf.adam_m_pol, h->buf.adam_v_pol, nullptr, h->n_pol,
+                             hp->policy_lr, hp->policy_step, hp->adam_beta1, hp->adam_beta2, hp->adam_eps, 0.0,
+                             (hipStream_t)stream, h->fin_p_pending ? &h->fin_p : nullptr);
+  g_phase = "";
+  h->fin_p_pending = false;
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -698,7 +807,7 @@ static int policy_mean_slabs(porl_iql* h, int B, int* nslab, hipStream_t s) {
 // The part of the policy step that does not depend on the value networks: the policy MLP's forward on the loaded
 // observations.  In data-parallel mode it runs while the value-gradient all-reduce is on the wire.
 int porl_iql_policy_prefetch(porl_iql* h, void* stream) {
-  PORL_TRY(check_ready(h, true));
+  PORL_TRY(check_ready(h, true)); DevGuard _dg(h->device);
   if (!h->have_pol_target) PORL_FAIL(PORL_ERR_INVALID, "policy step needs pol_target in porl_iql_load_batch");
   hipStream_t s = (hipStream_t)stream;
   const int B = h->batch, S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden;
@@ -708,7 +817,7 @@ int porl_iql_policy_prefetch(porl_iql* h, void* stream) {
   int parts = 0;
   for (int l = 0; l < L; ++l) {
     FwdNet f{};
-    if (l == 0) { f.in = W + ws.xs; f.ldin = h->Sp; }
+    if (l == 0) { f.in = W + ws.xs_slot[h->slot]; f.ldin = h->Sp; }
     else { f.in = W + ws.act_p[l - 1]; f.ldin = h->Hp; }
     f.W = Pp + h->pol.w[l]; f.b = Pp + h->pol.b[l];
     f.out = W + ws.act_p[l]; f.headw = nullptr; f.headout = nullptr;
@@ -719,11 +828,8 @@ int porl_iql_policy_prefetch(porl_iql* h, void* stream) {
   return PORL_OK;
 }
 
-int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
-  PORL_TRY(check_ready(h, true));
-  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+static int policy_backward_impl(porl_iql* h, const porl_iql_hyper* hp, hipStream_t s, ReduceArgs* defer) {
   if (!h->have_pol_target) PORL_FAIL(PORL_ERR_INVALID, "policy step needs pol_target in porl_iql_load_batch");
-  hipStream_t s = (hipStream_t)stream;
   const int B = h->batch, S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden, D = h->cfg.pol_out_dim;
   const int Hp = h->Hp, Dp = h->Dp;
   float* W = h->buf.workspace;
@@ -744,35 +850,39 @@ int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream
     const bool last = l == L - 1;
     for (int i = 0; i < 2; ++i) {
       FwdNet& f = nets[i];
-      if (l == 0) { f.in = W + ws.xs; f.ldin = h->Sp; }
-      else { f.in = W + ws.act_t[i][(l - 1) & 1]; f.ldin = Hp; }       // target scratch is free now
+      if (l == 0) { f.in = W + ws.xs_slot[h->slot]; f.ldin = h->Sp; }
+      else { f.in = W + ws.act_q[i][(l - 1) & 1]; f.ldin = Hp; }
       f.W = Pv + h->v[i].w[l]; f.b = Pv + h->v[i].b[l];
-      f.out = (last && !LN) ? nullptr : W + ws.act_t[i][l & 1];
-      f.headw = Pv + h->v[i].w[L]; f.headout = W + ws.hp_v[i];
+      f.out = (last && !LN) ? nullptr : W + ws.act_q[i][l & 1];
+      f.headw = Pv + h->v[i].w[L]; f.headout = W + ws.hp_q[i];
       if (LN) { f.ln_g = Pv + h->v[i].lnw[l]; f.ln_b = Pv + h->v[i].lnb[l]; }
     }
     FwdNet& f = nets[2];
-    if (l == 0) { f.in = W + ws.xs; f.ldin = h->Sp; }
+    if (l == 0) { f.in = W + ws.xs_slot[h->slot]; f.ldin = h->Sp; }
     else { f.in = W + ws.act_p[l - 1]; f.ldin = Hp; }
     f.W = Pp + h->pol.w[l]; f.b = Pp + h->pol.b[l];
     f.out = W + ws.act_p[l]; f.headw = nullptr; f.headout = nullptr;
+    g_phase = l == 0 ? "P1.L0fwd:" : "P2.fwd:";
     PORL_TRY(fwd_hidden_layer(h, nets, pre ? 2 : 3, B, K, last, &parts, s));
   }
   int nslab = h->pol_nslab;
+  g_phase = "P3.mean:";
   if (!pre) PORL_TRY(policy_mean_slabs(h, B, &nslab, s));
+  g_phase = "P4.";
 
   // -- advantage weights, NLL, dL/dmean, dL/dlog_std --------------------------------------------------
   const int nblk = cdiv(B, NLL_ROWS_PER_BLOCK);
   {
     PolicyNllArgs a{};
-    for (int i = 0; i < 2; ++i) { a.hp_v[i] = W + ws.hp_v[i]; a.b_v[i] = Pv + h->v[i].b[L]; }
-    a.parts = parts; a.target_v = W + ws.target_v;
+    for (int i = 0; i < 2; ++i) { a.hp_v[i] = W + ws.hp_q[i]; a.b_v[i] = Pv + h->v[i].b[L]; }
+    a.parts = parts; a.target_v = W + ws.target_v_slot[h->slot];
     a.mean_slab = W + ws.slab_mean; a.nslab = nslab; a.slab_stride = (long)B * Dp;
     a.mean_bias = Pp + h->pol.b[L]; a.log_std = Pp + h->logstd_off;
-    a.x = W + ws.xt; a.ldx = Dp; a.dmean = W + ws.dmu; a.ldd = Dp;
+    a.x = W + ws.xt_slot[h->slot]; a.ldx = Dp; a.dmean = W + ws.dmu; a.ldd = Dp;
     a.part_loss = W + ws.part_loss; a.part_min = W + ws.part_min; a.part_dls = W + ws.part_dls;
     a.B = B; a.D = D; a.ldm = Dp; a.tanh_mean = h->cfg.pol_tanh; a.weight_mode = h->cfg.weight_mode;
     a.alpha = hp->alpha; a.inv_batch = hp->inv_batch; a.rows_per_block = NLL_ROWS_PER_BLOCK;
+    ProfScope ps("policy_nll_kernel", s, 0.0, 4.0 * B * (nslab + 2.0) * Dp);
     hipLaunchKernelGGL(policy_nll_kernel, dim3(nblk), dim3(256), 0, s, a);
     PORL_HIP(hipGetLastError());
   }
@@ -802,12 +912,13 @@ int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream
       add_reduce(red, Gp + h->pol.w[L], slabW, (long)D * H, (long)D * H, sk);
       add_reduce(red, Gp + h->pol.b[L], slabC, D, D, sk);
     }
+    g_phase = "P5.outbwd:";
     PORL_TRY(launch_group(g, tile, s));
   }
   for (int l = L - 1; l >= 0; --l) {
     const int Kin = l == 0 ? S : H;
     const float* dz = W + ws.dz_p[l & 1];
-    const float* in = l == 0 ? W + ws.xs : W + ws.act_p[l - 1];
+    const float* in = l == 0 ? W + ws.xs_slot[h->slot] : W + ws.act_p[l - 1];
     const int ldin = l == 0 ? h->Sp : Hp;
     GemmGroup g{};
     g.p[g.nprob] = make_prob(GEMM_TN, dz, Hp, in, ldin, Gp + h->pol.w[l], Kin, H, Kin, B);
@@ -824,24 +935,50 @@ int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream
       const int sk = pick_splitk(H, Kin, B, 1, bm, bn);
       if (sk > 1) {
         const int64_t per = (int64_t)H * Kin;
-        float* slabW = W + ws.slab_a;
+        float* slabW = W + ws.slab_pa;
         float* slabC = slabW + (int64_t)SK_MAX * per;
         g.p[0].splitk = sk; g.p[0].C = slabW; g.p[0].colsum = slabC;
         add_reduce(red, Gp + h->pol.w[0], slabW, per, per, sk);
         add_reduce(red, Gp + h->pol.b[0], slabC, H, H, sk);
       }
     }
+    g_phase = l == 0 ? "P7.dW0:" : "P6.bwd:";
     PORL_TRY(launch_group(g, tile, s));
   }
-  PORL_TRY(launch_reduce(red, s));
+  g_phase = "P8.combine:";
+  if (defer) *defer = red;
+  else PORL_TRY(launch_reduce(red, s));
+  g_phase = "";
   return PORL_OK;
 }
 
+int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
+  PORL_TRY(check_ready(h, true)); DevGuard _dg(h->device);
+  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+  const bool fold = (h->mode & PORL_IQL_MODE_FOLD_COMBINE) != 0;
+  h->fin_p = ReduceArgs{};
+  PORL_TRY(policy_backward_impl(h, hp, (hipStream_t)stream, fold ? &h->fin_p : nullptr));
+  h->fin_p_pending = fold;
+  return PORL_OK;
+}
+
+// The whole update in one call.  Same arithmetic as the four phase calls; the two slab / partial-sum combines are
+// folded into the Adam launches instead of running as launches of their own.
 int porl_iql_step(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
-  PORL_TRY(porl_iql_value_backward(h, hp, stream));
-  PORL_TRY(porl_iql_value_apply(h, hp, stream));
-  PORL_TRY(porl_iql_policy_backward(h, hp, stream));
-  PORL_TRY(porl_iql_policy_apply(h, hp, stream));
+  PORL_TRY(check_ready(h, true)); DevGuard _dg(h->device);
+  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+  hipStream_t s = (hipStream_t)stream;
+  ReduceArgs fin{};
+  PORL_TRY(value_backward_impl(h, hp, s, &fin));
+  g_phase = "V8.";
+  PORL_TRY(adam_launch(h->buf.params_vf, h->buf.grads_vf, h->buf.adam_m_vf, h->buf.adam_v_vf, h->buf.params_tgt, h->n_vf,
+                       hp->value_lr, hp->value_step, hp->adam_beta1, hp->adam_beta2, hp->adam_eps, hp->ema_beta, s, &fin));
+  fin = ReduceArgs{};
+  PORL_TRY(policy_backward_impl(h, hp, s, &fin));
+  g_phase = "P9.";
+  PORL_TRY(adam_launch(h->buf.params_pol, h->buf.grads_pol, h->buf.adam_m_pol, h->buf.adam_v_pol, nullptr, h->n_pol,
+                       hp->policy_lr, hp->policy_step, hp->adam_beta1, hp->adam_beta2, hp->adam_eps, 0.0, s, &fin));
+  g_phase = "";
   return PORL_OK;
 }
 
@@ -861,7 +998,7 @@ static int pack_x(porl_iql* h, const float* x, int64_t x_rs, int batch, int64_t 
 
 int porl_iql_forward_value(porl_iql* h, int which, const float* x, int64_t x_rs, int32_t batch, float* v1_out,
                            float* v2_out, void* stream) {
-  PORL_TRY(check_ready(h, false));
+  PORL_TRY(check_ready(h, false)); DevGuard _dg(h->device);
   if (!v1_out || !v2_out) PORL_FAIL(PORL_ERR_INVALID, "null output");
   hipStream_t s = (hipStream_t)stream;
   // uses the s' staging buffer and the target scratch activations; invalidates a loaded minibatch
@@ -893,7 +1030,7 @@ int porl_iql_forward_value(porl_iql* h, int which, const float* x, int64_t x_rs,
 
 int porl_iql_forward_policy(porl_iql* h, const float* x, int64_t x_rs, int32_t batch, float* mean_out,
                             int64_t mean_rs, void* stream) {
-  PORL_TRY(check_ready(h, false));
+  PORL_TRY(check_ready(h, false)); DevGuard _dg(h->device);
   if (!mean_out) PORL_FAIL(PORL_ERR_INVALID, "null output");
   hipStream_t s = (hipStream_t)stream;
   PORL_TRY(pack_x(h, x, x_rs, batch, h->ws.xn, s));
@@ -926,6 +1063,7 @@ int porl_gemm_f32(int mode, int tile, int32_t M, int32_t N, int32_t K, const flo
   if (M < 1 || N < 1 || K < 0 || !A || !B || !C) PORL_FAIL(PORL_ERR_INVALID, "bad GEMM arguments");
   if (splitk > 1 && !slab) PORL_FAIL(PORL_ERR_INVALID, "splitk > 1 needs a slab buffer");
   if (splitk > 1 && ldc != N) PORL_FAIL(PORL_ERR_INVALID, "splitk > 1 needs a dense C (ldc == N)");
+  DevGuard _dg(device_of(C));
   hipStream_t s = (hipStream_t)stream;
   GemmGroup g{};
   g.nprob = 1;
@@ -953,13 +1091,15 @@ int porl_adam_ema(float* p, const float* g, float* m, float* v, float* target, i
   if (!p || !g || !m || !v) PORL_FAIL(PORL_ERR_INVALID, "null buffer");
   if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (target && !aligned16(target)))
     PORL_FAIL(PORL_ERR_INVALID, "buffers must be 16-byte aligned");
-  return adam_launch(p, g, m, v, target, n, lr, step, beta1, beta2, eps, ema_beta, (hipStream_t)stream);
+  DevGuard _dg(device_of(p));
+  return adam_launch(p, const_cast<float*>(g), m, v, target, n, lr, step, beta1, beta2, eps, ema_beta, (hipStream_t)stream);
 }
 
 int porl_gather_rows(const float* rows, int64_t row_stride, const int64_t* idx, int32_t n, int32_t width, float* out,
                      int64_t out_stride, void* stream) {
   if (!rows || !idx || !out || n < 0 || width < 1) PORL_FAIL(PORL_ERR_INVALID, "bad gather arguments");
   if (n == 0) return PORL_OK;
+  DevGuard _dg(device_of(out));
   const int blocks = std::min(cdiv(n, 4), 2048);
   hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, (long)row_stride, idx, n,
                      width, out, (long)out_stride);
@@ -972,6 +1112,7 @@ int porl_sample_indices(int64_t n_rows, int32_t batch, uint64_t seed, uint64_t s
   if (n_rows < 1 || batch < 1 || batch > n_rows || !out) PORL_FAIL(PORL_ERR_INVALID, "need 1 <= batch <= n_rows");
   if (n_rows > (int64_t(1) << 40)) PORL_FAIL(PORL_ERR_INVALID, "n_rows too large");
   const int hb = feistel_half_bits(n_rows);
+  DevGuard _dg(device_of(out));
   hipLaunchKernelGGL(sample_indices_kernel, dim3(cdiv(batch, 256)), dim3(256), 0, (hipStream_t)stream, n_rows, batch,
                      seed, step, hb, base, (int64_t)0, out);
   PORL_HIP(hipGetLastError());
@@ -984,6 +1125,7 @@ int porl_epoch_indices(int64_t n_rows, int64_t first, int32_t count, uint64_t se
     PORL_FAIL(PORL_ERR_INVALID, "need 0 <= first, 1 <= count, first + count <= n_rows");
   if (n_rows > (int64_t(1) << 40)) PORL_FAIL(PORL_ERR_INVALID, "n_rows too large");
   const int hb = feistel_half_bits(n_rows);
+  DevGuard _dg(device_of(out));
   hipLaunchKernelGGL(sample_indices_kernel, dim3(cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, n_rows, count,
                      seed, epoch, hb, base, first, out);
   PORL_HIP(hipGetLastError());
@@ -995,6 +1137,7 @@ int porl_per_update(double* tree, int64_t capacity, const int64_t* tree_idx, con
                     double alpha, int32_t* stamp, void* stream) {
   if (!tree || !tree_idx || !td_error || !stamp || capacity < 1 || n < 0) PORL_FAIL(PORL_ERR_INVALID, "bad arguments");
   if (n == 0) return PORL_OK;
+  DevGuard _dg(device_of(tree));
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(per_stamp_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, tree_idx, n, capacity, stamp);
   hipLaunchKernelGGL(per_set_leaves_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, tree, tree_idx, td_error, n, capacity, eps,
@@ -1010,6 +1153,7 @@ int porl_per_sample(const double* tree, int64_t capacity, const double* u, int32
                     int64_t* out_idx, double* out_prio, float* out_w, void* stream) {
   if (!tree || !u || !out_idx || !out_prio || !out_w || capacity < 1 || batch < 1 || n_entries < 1)
     PORL_FAIL(PORL_ERR_INVALID, "bad arguments");
+  DevGuard _dg(device_of(tree));
   PerSampleArgs a{tree, capacity, u, batch, n_entries, beta, out_idx, out_prio, out_w};
   hipLaunchKernelGGL(per_sample_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   PORL_HIP(hipGetLastError());
@@ -1035,6 +1179,7 @@ int porl_state2costmap(float* state, int64_t state_rs, int32_t batch, int32_t n_
                         void* stream) {
   if (!state || !out || batch < 1 || n_ang < 4 || n_dist < 4) PORL_FAIL(PORL_ERR_INVALID, "bad costmap arguments");
   if (batch > 65535) PORL_FAIL(PORL_ERR_INVALID, "batch > 65535");
+  DevGuard _dg(device_of(out));
   hipStream_t s = (hipStream_t)stream;
   // constants exactly as util/costmap.py:19-20,34,45 forms them (python doubles rounded to fp32 at the tensor op)
   const double pi = 3.14159265358979323846;
@@ -1091,6 +1236,7 @@ struct porl_qnet {
   std::vector<TensorInfo> tensors;
   porl_qnet_buffers buf{};
   bool bound = false;
+  int device = -1;
   int batch = 0;
   int Sp = 0, Ap = 0, ld[PORL_MAX_HIDDEN + 2] = {0};     // padded leading dims per layer output
   struct {
@@ -1199,6 +1345,7 @@ int porl_qnet_bind(porl_qnet* h, const porl_qnet_buffers* b) {
   }
   h->buf = *b;
   h->bound = true;
+  h->device = device_of(b->workspace);
   h->batch = 0;
   h->fslab_clean = false;
   return PORL_OK;
@@ -1214,7 +1361,7 @@ static int qnet_ready(const porl_qnet* h, bool need_batch) {
 int porl_qnet_load_batch(porl_qnet* h, int32_t batch, const float* states, int64_t s_rs, const int64_t* actions,
                          int64_t a_rs, const float* rewards, int64_t r_rs, const float* next_states, int64_t n_rs,
                          const float* dones, int64_t d_rs, void* stream) {
-  PORL_TRY(qnet_ready(h, false));
+  PORL_TRY(qnet_ready(h, false)); DevGuard _dg(h->device);
   if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
   if (!states) PORL_FAIL(PORL_ERR_INVALID, "null states");
   float* W = h->buf.workspace;
@@ -1317,7 +1464,7 @@ static int qnet_fused_backward(porl_qnet* h, const porl_qnet_hyper* hp, int B, c
 }
 
 int porl_qnet_cql_backward(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
-  PORL_TRY(qnet_ready(h, true));
+  PORL_TRY(qnet_ready(h, true)); DevGuard _dg(h->device);
   if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
   hipStream_t s = (hipStream_t)stream;
   const int B = h->batch, L = h->cfg.n_hidden, A = h->cfg.n_actions;
@@ -1386,14 +1533,14 @@ int porl_qnet_cql_backward(porl_qnet* h, const porl_qnet_hyper* hp, void* stream
 }
 
 int porl_qnet_apply(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
-  PORL_TRY(qnet_ready(h, false));
+  PORL_TRY(qnet_ready(h, false)); DevGuard _dg(h->device);
   if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
   return adam_launch(h->buf.params, h->buf.grads, h->buf.adam_m, h->buf.adam_v, nullptr, h->n_params, hp->lr, hp->step,
                      hp->adam_beta1, hp->adam_beta2, hp->adam_eps, 0.0, (hipStream_t)stream);
 }
 
 int porl_qnet_learn(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
-  PORL_TRY(qnet_ready(h, true));
+  PORL_TRY(qnet_ready(h, true)); DevGuard _dg(h->device);
   if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
   if (h->fused_ok && g_qnet_fused) {
     float* W = h->buf.workspace;
@@ -1408,7 +1555,7 @@ int porl_qnet_learn(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
 int porl_qnet_learn_indexed(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions, const float* rewards,
                             const float* next_states, int64_t n_rs, const float* dones, const int64_t* idx, int32_t batch,
                             const porl_qnet_hyper* hp, void* stream) {
-  PORL_TRY(qnet_ready(h, false));
+  PORL_TRY(qnet_ready(h, false)); DevGuard _dg(h->device);
   if (!hp || !states || !actions || !rewards || !next_states || !dones) PORL_FAIL(PORL_ERR_INVALID, "null argument");
   if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
   if (!h->fused_ok || !g_qnet_fused)
@@ -1421,7 +1568,7 @@ int porl_qnet_learn_indexed(porl_qnet* h, const float* states, int64_t s_rs, con
 int porl_qnet_learn_variant(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions, const float* rewards,
                             const float* next_states, int64_t n_rs, const float* dones, const int64_t* idx, int32_t batch,
                             const porl_qnet_hyper* hp, const porl_qnet_variant* variant, void* stream) {
-  PORL_TRY(qnet_ready(h, false));
+  PORL_TRY(qnet_ready(h, false)); DevGuard _dg(h->device);
   if (!hp || !states || !actions || !rewards || !next_states || !dones || !variant) PORL_FAIL(PORL_ERR_INVALID, "null argument");
   if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
   if (!h->fused_ok || !g_qnet_fused) PORL_FAIL(PORL_ERR_UNSUPPORTED, "the DQN variants run on the one-launch kernel only");
@@ -1430,7 +1577,7 @@ int porl_qnet_learn_variant(porl_qnet* h, const float* states, int64_t s_rs, con
 }
 
 int porl_qnet_sync_target(porl_qnet* h, void* stream) {
-  PORL_TRY(qnet_ready(h, false));
+  PORL_TRY(qnet_ready(h, false)); DevGuard _dg(h->device);
   PORL_HIP(hipMemcpyAsync(h->buf.params_tgt, h->buf.params, sizeof(float) * h->n_params, hipMemcpyDeviceToDevice,
                           (hipStream_t)stream));
   return PORL_OK;
@@ -1439,7 +1586,7 @@ int porl_qnet_sync_target(porl_qnet* h, void* stream) {
 // Q(s, .) for a loaded batch of states (which = 0 online, 1 target) -> q_out (batch, n_actions), row stride q_rs
 int porl_qnet_forward(porl_qnet* h, int which, const float* states, int64_t s_rs, int32_t batch, float* q_out,
                       int64_t q_rs, void* stream) {
-  PORL_TRY(qnet_ready(h, false));
+  PORL_TRY(qnet_ready(h, false)); DevGuard _dg(h->device);
   if (!q_out) PORL_FAIL(PORL_ERR_INVALID, "null output");
   hipStream_t s = (hipStream_t)stream;
   PORL_TRY(porl_qnet_load_batch(h, batch, states, s_rs, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, stream));
@@ -1465,7 +1612,7 @@ int porl_qnet_forward(porl_qnet* h, int which, const float* states, int64_t s_rs
 // mean_b( logsumexp_a Q(s_b, a) - ln A - Q(s_b, a_b) ) -> out[0]   (compute_cql_penalty)
 int porl_qnet_penalty(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions, int64_t a_rs,
                       int32_t batch, float* out, void* stream) {
-  PORL_TRY(qnet_ready(h, false));
+  PORL_TRY(qnet_ready(h, false)); DevGuard _dg(h->device);
   if (!out || !actions) PORL_FAIL(PORL_ERR_INVALID, "null argument");
   hipStream_t s = (hipStream_t)stream;
   PORL_TRY(porl_qnet_load_batch(h, batch, states, s_rs, actions, a_rs, nullptr, 0, nullptr, 0, nullptr, 0, stream));

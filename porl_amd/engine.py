@@ -25,6 +25,7 @@ def _norm_device(device):
 
 class IqlEngine:
     GROUP_VF, GROUP_POL = 0, 1
+    MODE_TWO_SLOTS, MODE_FOLD_COMBINE = 1, 2          # include/porl_hip.h: PORL_IQL_MODE_*
 
     def __init__(self, obs_dim, pol_out_dim, hidden_dim, n_hidden, layer_norm=False, pol_tanh=False,
                  weight_mode=0, max_batch=1024, device="cpu"):
@@ -38,7 +39,36 @@ class IqlEngine:
         self.n_vf = int(self._lib.porl_iql_group_floats(h, 0))
         self.n_pol = int(self._lib.porl_iql_group_floats(h, 1))
         self._bound = False
+        self._mode = 0
+        # pipelined updates (agent/_iql.py): the policy phase of update t runs on `side_stream` while the value phase
+        # of update t+1 runs on the caller's stream; `_policy_done` is the event the side stream recorded last
+        self._side = None
+        self._policy_done = None
+        self._events = []
         self._alloc()
+
+    # -- streams -----------------------------------------------------------------------------------
+    def side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def event(self, i):
+        """Small ring of reusable events (re-recording an event does not disturb waits already enqueued on it)."""
+        while len(self._events) <= i:
+            self._events.append(torch.cuda.Event(enable_timing=False, blocking=False))
+        return self._events[i]
+
+    def join(self):
+        """Order the current stream behind an outstanding policy phase on the side stream (no host wait)."""
+        ev, self._policy_done = self._policy_done, None
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def set_mode(self, mode):
+        if mode != self._mode:
+            N.check(self._lib.porl_iql_set_mode(self._h, int(mode)), "porl_iql_set_mode")
+            self._mode = mode
 
     # -- memory ------------------------------------------------------------------------------------
     def _alloc(self):
@@ -64,12 +94,16 @@ class IqlEngine:
             self.adam_m_vf, self.adam_v_vf, self.adam_m_pol, self.adam_v_pol, self.workspace, self.stats)])
         N.check(self._lib.porl_iql_bind(self._h, C.byref(b)), "porl_iql_bind")
         self._bound = True
+        self._mode = 0
+        N.check(self._lib.porl_iql_set_mode(self._h, 0), "porl_iql_set_mode")
 
     def to(self, device):
         """Move every flat tensor; views handed out earlier must be re-created by the caller."""
         device = _norm_device(device)
         if device == self.device:
             return self
+        self.join()
+        self._side, self._events = None, []
         for name in ("params_vf", "params_tgt", "params_pol", "grads_vf", "grads_pol", "adam_m_vf",
                      "adam_v_vf", "adam_m_pol", "adam_v_pol", "stats"):
             setattr(self, name, getattr(self, name).to(device))
@@ -129,7 +163,7 @@ class IqlEngine:
             self._h, B, N.ptr(obs), obs.stride(0), N.ptr(next_obs), next_obs.stride(0),
             N.ptr(rew), rew.stride(0), N.ptr(term), term.stride(0),
             N.ptr(pol_target), 0 if pol_target is None else pol_target.stride(0),
-            N.current_stream_ptr()), "porl_iql_load_batch")
+            N.current_stream_ptr(self.device)), "porl_iql_load_batch")
         return B
 
     def load_batch_sampled(self, rows, batch, seed, step, act_dim, target_is_action, idx_out=None):
@@ -139,7 +173,7 @@ class IqlEngine:
             raise RuntimeError("replay rows must be a 2-D fp32 tensor on the engine's device")
         N.check(self._lib.porl_iql_load_batch_sampled(
             self._h, batch, N.ptr(rows), rows.stride(0), rows.shape[0], act_dim, int(target_is_action),
-            seed & 0xFFFFFFFFFFFFFFFF, step, N.ptr(idx_out), N.current_stream_ptr()), "porl_iql_load_batch_sampled")
+            seed & 0xFFFFFFFFFFFFFFFF, step, N.ptr(idx_out), N.current_stream_ptr(self.device)), "porl_iql_load_batch_sampled")
         return batch
 
     def set_stats(self, stats):
@@ -157,7 +191,7 @@ class IqlEngine:
         return N.IqlHyper(**d)
 
     def _phase(self, name, hp):
-        N.check(getattr(self._lib, name)(self._h, C.byref(hp), N.current_stream_ptr()), name)
+        N.check(getattr(self._lib, name)(self._h, C.byref(hp), N.current_stream_ptr(self.device)), name)
 
     def value_backward(self, hp): self._phase("porl_iql_value_backward", hp)
     def value_apply(self, hp): self._phase("porl_iql_value_apply", hp)
@@ -166,26 +200,28 @@ class IqlEngine:
     def step(self, hp): self._phase("porl_iql_step", hp)
 
     def policy_prefetch(self):
-        N.check(self._lib.porl_iql_policy_prefetch(self._h, N.current_stream_ptr()), "porl_iql_policy_prefetch")
+        N.check(self._lib.porl_iql_policy_prefetch(self._h, N.current_stream_ptr(self.device)), "porl_iql_policy_prefetch")
 
     # -- forward-only ------------------------------------------------------------------------------
     def forward_value(self, x, target=False):
         self._ensure_bound()
+        self.join()
         x = self._mat(x, self.cfg.obs_dim, "state")
         B = x.shape[0]
         v1 = torch.empty(B, dtype=torch.float32, device=self.device)
         v2 = torch.empty_like(v1)
         N.check(self._lib.porl_iql_forward_value(self._h, int(target), N.ptr(x), x.stride(0), B, N.ptr(v1),
-                                                 N.ptr(v2), N.current_stream_ptr()), "porl_iql_forward_value")
+                                                 N.ptr(v2), N.current_stream_ptr(self.device)), "porl_iql_forward_value")
         return v1, v2
 
     def forward_policy(self, x):
         self._ensure_bound()
+        self.join()
         x = self._mat(x, self.cfg.obs_dim, "obs")
         B, D = x.shape[0], self.cfg.pol_out_dim
         mean = torch.empty(B, D, dtype=torch.float32, device=self.device)
         N.check(self._lib.porl_iql_forward_policy(self._h, N.ptr(x), x.stride(0), B, N.ptr(mean), D,
-                                                  N.current_stream_ptr()), "porl_iql_forward_policy")
+                                                  N.current_stream_ptr(self.device)), "porl_iql_forward_policy")
         return mean
 
     def __del__(self):
@@ -203,12 +239,12 @@ def gemm_f32(mode, A, B, M, N_, K, lda, ldb, C_out, ldc, bias=None, act=0, mask=
     """Test/utility entry: raw pointers of torch tensors, see include/porl_hip.h:porl_gemm_f32."""
     N.check(N.lib().porl_gemm_f32(mode, tile, M, N_, K, N.ptr(A), lda, N.ptr(B), ldb, N.ptr(C_out), ldc,
                                   N.ptr(bias), act, N.ptr(mask), ldmask, splitk, N.ptr(slab),
-                                  N.current_stream_ptr()), "porl_gemm_f32")
+                                  N.current_stream_ptr(C_out)), "porl_gemm_f32")
 
 
 def adam_ema(p, g, m, v, target, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, ema_beta=0.0):
     N.check(N.lib().porl_adam_ema(N.ptr(p), N.ptr(g), N.ptr(m), N.ptr(v), N.ptr(target), p.numel(), lr, step,
-                                  beta1, beta2, eps, ema_beta, N.current_stream_ptr()), "porl_adam_ema")
+                                  beta1, beta2, eps, ema_beta, N.current_stream_ptr(p)), "porl_adam_ema")
 
 
 def gather_rows(rows, idx, out=None):
@@ -219,7 +255,7 @@ def gather_rows(rows, idx, out=None):
     if out is None:
         out = torch.empty(n, w, dtype=rows.dtype, device=rows.device)
     N.check(N.lib().porl_gather_rows(N.ptr(rows), rows.stride(0), N.ptr(idx), n, w, N.ptr(out), out.stride(0),
-                                     N.current_stream_ptr()), "porl_gather_rows")
+                                     N.current_stream_ptr(out)), "porl_gather_rows")
     return out
 
 
@@ -227,7 +263,7 @@ def sample_indices(n_rows, batch, seed, step, out=None, base=0, device="cuda"):
     """`batch` distinct row indices in [base, base + n_rows) drawn on the device (int64)."""
     if out is None:
         out = torch.empty(batch, dtype=torch.int64, device=device)
-    N.check(N.lib().porl_sample_indices(n_rows, batch, seed, step, base, N.ptr(out), N.current_stream_ptr()),
+    N.check(N.lib().porl_sample_indices(n_rows, batch, seed, step, base, N.ptr(out), N.current_stream_ptr(out)),
             "porl_sample_indices")
     return out
 
@@ -236,7 +272,7 @@ def epoch_indices(n_rows, first, count, seed, epoch, out=None, base=0, device="c
     """Positions first..first+count-1 of the keyed permutation (seed, epoch) of [0, n_rows) (int64, on the device)."""
     if out is None:
         out = torch.empty(count, dtype=torch.int64, device=device)
-    N.check(N.lib().porl_epoch_indices(n_rows, first, count, seed, epoch, base, N.ptr(out), N.current_stream_ptr()),
+    N.check(N.lib().porl_epoch_indices(n_rows, first, count, seed, epoch, base, N.ptr(out), N.current_stream_ptr(out)),
             "porl_epoch_indices")
     return out
 

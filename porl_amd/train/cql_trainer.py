@@ -94,15 +94,15 @@ class QnetEngine:
         N.check(self._lib.porl_qnet_load_batch(self._h, B, N.ptr(states), states.stride(0), N.ptr(actions),
                                                actions.stride(0), N.ptr(rewards), rewards.stride(0),
                                                N.ptr(next_states), next_states.stride(0), N.ptr(dones),
-                                               dones.stride(0), N.current_stream_ptr()), "porl_qnet_load_batch")
+                                               dones.stride(0), N.current_stream_ptr(self.device)), "porl_qnet_load_batch")
         return B
 
     def hyper(self, gamma, alpha, inv_batch, step, lr, betas=(0.9, 0.999), eps=1e-8):
         return N.QnetHyper(gamma, alpha, inv_batch, step, lr, betas[0], betas[1], eps)
 
-    def cql_backward(self, hp): N.check(self._lib.porl_qnet_cql_backward(self._h, C.byref(hp), N.current_stream_ptr()), "porl_qnet_cql_backward")
-    def apply(self, hp): N.check(self._lib.porl_qnet_apply(self._h, C.byref(hp), N.current_stream_ptr()), "porl_qnet_apply")
-    def learn(self, hp): N.check(self._lib.porl_qnet_learn(self._h, C.byref(hp), N.current_stream_ptr()), "porl_qnet_learn")
+    def cql_backward(self, hp): N.check(self._lib.porl_qnet_cql_backward(self._h, C.byref(hp), N.current_stream_ptr(self.device)), "porl_qnet_cql_backward")
+    def apply(self, hp): N.check(self._lib.porl_qnet_apply(self._h, C.byref(hp), N.current_stream_ptr(self.device)), "porl_qnet_apply")
+    def learn(self, hp): N.check(self._lib.porl_qnet_learn(self._h, C.byref(hp), N.current_stream_ptr(self.device)), "porl_qnet_learn")
 
     def learn_indexed(self, hp, states, actions, rewards, next_states, dones, idx, variant=None):
         """learn() on rows `idx` (int64, device) of device-resident replay arrays, gathered inside the step kernel.
@@ -121,25 +121,25 @@ class QnetEngine:
         if variant is None:
             N.check(self._lib.porl_qnet_learn_indexed(self._h, N.ptr(states), self.cfg.state_dim, N.ptr(actions),
                                                       N.ptr(rewards), N.ptr(next_states), self.cfg.state_dim, N.ptr(dones),
-                                                      N.ptr(idx), B, C.byref(hp), N.current_stream_ptr()),
+                                                      N.ptr(idx), B, C.byref(hp), N.current_stream_ptr(self.device)),
                     "porl_qnet_learn_indexed")
         else:
             N.check(self._lib.porl_qnet_learn_variant(self._h, N.ptr(states), self.cfg.state_dim, N.ptr(actions),
                                                       N.ptr(rewards), N.ptr(next_states), self.cfg.state_dim, N.ptr(dones),
                                                       N.ptr(idx), B, C.byref(hp), C.byref(variant),
-                                                      N.current_stream_ptr()), "porl_qnet_learn_variant")
+                                                      N.current_stream_ptr(self.device)), "porl_qnet_learn_variant")
         return B
 
     def sync_target(self):
         self._ensure_bound()
-        N.check(self._lib.porl_qnet_sync_target(self._h, N.current_stream_ptr()), "porl_qnet_sync_target")
+        N.check(self._lib.porl_qnet_sync_target(self._h, N.current_stream_ptr(self.device)), "porl_qnet_sync_target")
 
     def forward(self, x, which=0):
         self._ensure_bound()
         x = self._states(x)
         q = torch.empty(x.shape[0], self.cfg.n_actions, dtype=torch.float32, device=self.device)
         N.check(self._lib.porl_qnet_forward(self._h, which, N.ptr(x), x.stride(0), x.shape[0], N.ptr(q),
-                                            self.cfg.n_actions, N.current_stream_ptr()), "porl_qnet_forward")
+                                            self.cfg.n_actions, N.current_stream_ptr(self.device)), "porl_qnet_forward")
         return q
 
     def penalty(self, states, actions):
@@ -149,7 +149,7 @@ class QnetEngine:
         out = torch.empty(1, dtype=torch.float32, device=self.device)
         N.check(self._lib.porl_qnet_penalty(self._h, N.ptr(states), states.stride(0), N.ptr(actions),
                                             actions.stride(0), states.shape[0], N.ptr(out),
-                                            N.current_stream_ptr()), "porl_qnet_penalty")
+                                            N.current_stream_ptr(self.device)), "porl_qnet_penalty")
         return out[0]
 
     def __del__(self):

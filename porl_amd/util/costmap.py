@@ -23,5 +23,5 @@ def state2costmap(state, angle_bins=360, dist_bins=256):
     b = state.shape[0]
     out = torch.empty(b, 3, angle_bins, dist_bins, dtype=torch.float32, device=state.device)
     N.check(N.lib().porl_state2costmap(N.ptr(state), state.stride(0), b, angle_bins, dist_bins, N.ptr(out),
-                                       N.current_stream_ptr()), "porl_state2costmap")
+                                       N.current_stream_ptr(state)), "porl_state2costmap")
     return out

@@ -40,7 +40,7 @@ def _worker(rank, world, port, out_dir, async_mode=False):
     from porl_amd.util.synth import split_rows
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     agent = _agent(BL)
-    agent.async_losses = async_mode                          # async: policy exchange overlapped, applied lazily
+    agent.async_losses = async_mode                          # async: pipelined, policy phase + its exchange on the side stream
     rows = torch.from_numpy(_rows()).cuda()
     losses = []
     for k in range(STEPS):
@@ -50,7 +50,7 @@ def _worker(rank, world, port, out_dir, async_mode=False):
         out = agent.por_residual_update(s, sp, r, d)
         losses.append(tuple(out[:2].tolist()) if async_mode else out)
     if async_mode:
-        assert agent._deferred is not None                   # the last policy step is still pending ...
+        assert agent._engine._policy_done is not None        # the last policy phase is still on the side stream ...
     if rank == 0:                                            # ... and state_dict() completes it
         np.savez(os.path.join(out_dir, "dp.npz"), losses=np.array(losses),
                  **{k: v.cpu().numpy() for k, v in agent.state_dict().items()})

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, sub
+from conftest import checksum, load_golden, sub
 from oracle.por_oracle import PorOracle, sorl_oracle
 from porl_amd.util.synth import make_rows, split_rows
 
@@ -37,12 +37,13 @@ def _cmp_params(got, ref, atol=PARAM_ATOL):
     assert worst[1] <= atol, f"max-abs param error {worst[1]:.3e} at {worst[0]}"
 
 
-def _cmp_params_robust(got, truth, frac_tol=1e-3, elem_tol=2e-6, max_tol=5e-5):
+def _cmp_params_robust(got, truth, frac_tol=1e-3, elem_tol=2e-6, max_tol=PARAM_ATOL):
     """Large nets: compare with the fp64 oracle.  fp32 rounding can flip a ReLU mask bit (|z| ~ 1e-7) in
     a ~1e6-element activation matrix; a flipped unit moves one weight row by up to ~lr/10 through Adam.
     Any two fp32 implementations differ this way (the numpy fp32 oracle sits 1.2e-5 from fp64 on 731
     weights of BASELINE config 2 after 3 steps; the HIP path 4.6e-7).  So: all but a 1e-3 fraction of
-    every tensor within 2e-6 of the exact result, and nothing further than 5e-5 (half an Adam step)."""
+    every tensor within 2e-6 of the exact result, and nothing further than the 1e-5 bar (only the B=8192 case
+    passes a wider `max_tol`, for the reason stated there)."""
     for k, ref in truth.items():
         err = np.abs(got[k].astype(np.float64) - ref)
         frac = float((err > elem_tol).mean())
@@ -171,9 +172,9 @@ def test_por_phases_vs_oracle(S, H, L, B, ln):
 @pytest.mark.parametrize("name", ["por_s60_h256_b256", "por_s60_h1024_b256", "por_s60_h1024_b1024",
                                   "por_s60_h1024_b1024_ln"])
 def test_por_baseline_configs_vs_golden_losses(name):
-    """BASELINE configs 1/2 (H=1024, B=256/1024): losses against the reference's recorded values and
-    all 5.6 M parameters against the fp64 run of the oracle (whose fp32 run is pinned to the reference's
-    checksums in tests/test_oracle_golden.py)."""
+    """BASELINE configs 1/2 (H=1024, B=256/1024): losses against the reference's recorded values; ALL 5.6 M
+    parameters within 1e-5 max-abs (the north_star bar) of the fp64 run of the oracle; and, directly against the
+    reference, the 16 sampled elements + sums per tensor it recorded in `final_cks` (oracle/gen_golden.py)."""
     z, meta = load_golden(name)
     S, H, L, B, K, A = (int(meta[k]) for k in ("S", "H", "L", "B", "K", "A"))
     ln = bool(meta["layer_norm"])
@@ -188,7 +189,16 @@ def test_por_baseline_configs_vs_golden_losses(name):
         np.testing.assert_allclose(gl, z["g_loss"][k], rtol=LOSS_RTOL)
         sn, rn, spn, dn, _ = split_rows(rows_np[k * B:(k + 1) * B], S, A)
         o.por_residual_update(sn, spn, rn, dn)
-    _cmp_params_robust(_np_sd(agent), o.P)
+    got = _np_sd(agent)
+    _cmp_params(got, o.P, atol=PARAM_ATOL)                  # measured: 4.6e-7 at config 2
+    keys = [str(k) for k in z["keys"]]
+    assert list(got.keys()) == keys
+    for i, k in enumerate(keys):
+        mine, ref = checksum(got[k], i), z["final_cks"][i]
+        n = got[k].size
+        np.testing.assert_allclose(mine[2:], ref[2:], atol=PARAM_ATOL, rtol=0, err_msg=k)
+        assert abs(mine[0] - ref[0]) <= PARAM_ATOL * max(1.0, np.sqrt(n)), k
+        assert abs(mine[1] - ref[1]) <= PARAM_ATOL * max(1.0, np.sqrt(n)) * 4, k
 
 
 def test_por_forward_api_and_state_dict_roundtrip():
@@ -325,3 +335,56 @@ def test_por_global_batch_of_config4_on_one_gpu():
     # the first Adam step is lr * g / (|g| + 1e-8): for the handful of weights whose gradient is ~1e-8 the fp32 noise
     # of an 8192-row sum decides the sign, so a single element may be off by up to 2 * lr = 2e-4
     _cmp_params_robust(_np_sd(agent), o.P, max_tol=2.1e-4)
+
+
+def test_pipelined_updates_are_bit_identical_to_back_to_back_updates():
+    """async_losses=True issues the policy phase of update t on the engine's side stream and lets update t+1's value
+    phase run beside it (agent/_iql.py).  Same kernels on the same data in the same order per buffer: every loss,
+    parameter and Adam moment must equal the single-stream run bit for bit; state read right after an update
+    (optimizer state_dict, a policy forward) must already contain that update."""
+    S, A, B, H, K = 60, 2, 256, 256, 6
+    rows = torch.from_numpy(make_rows(K * B, S, A, seed=5)).to(DEV)
+    a_sync, a_pipe = _make_por(S, H, 2, B), _make_por(S, H, 2, B)
+    a_pipe.async_losses = True
+    hist = torch.zeros(K, 8, device=DEV)
+    want = []
+    for k in range(K):
+        s, r, sp, d, a = split_rows(rows[k * B:(k + 1) * B], S, A)
+        want.append(a_sync.por_residual_update(s, sp, r, d))
+        a_pipe._engine.set_stats(hist[k])
+        a_pipe.por_residual_update(s, sp, r, d)
+        if k == 2:                                  # mid-run reads see a consistent agent
+            sd_p = a_pipe.goal_policy_optimizer.state_dict()
+            sd_s = a_sync.goal_policy_optimizer.state_dict()
+            for i in sd_s["state"]:
+                assert torch.equal(sd_p["state"][i]["exp_avg"], sd_s["state"][i]["exp_avg"])
+                assert float(sd_p["state"][i]["step"]) == float(sd_s["state"][i]["step"]) == 3.0
+            assert torch.equal(a_pipe.goal_policy(s).mean, a_sync.goal_policy(s).mean)
+    assert a_pipe._engine._policy_done is not None
+    for (k1, v1), v2 in zip(a_pipe.state_dict().items(), a_sync.state_dict().values()):
+        assert torch.equal(v1, v2), k1
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(hist[:, :2].cpu().numpy(), np.array(want, dtype=np.float32))
+
+
+def test_engine_on_a_non_current_device_guard():
+    """The C entry points launch on the device that owns the engine's buffers, and the stream handed over is torch's
+    current stream OF THAT device — whatever the thread's current device is (_native.py:202)."""
+    if torch.cuda.device_count() < 2:
+        # one-GPU box: the guard's own logic still runs (device_of(workspace) == current device); check it is recorded
+        agent = _make_por(60, 64, 2, 32)
+        rows = torch.from_numpy(make_rows(32, 60, 2, seed=1)).to(DEV)
+        s, r, sp, d, a = split_rows(rows, 60, 2)
+        agent.por_residual_update(s, sp, r, d)
+        assert agent._engine.device.index == torch.cuda.current_device()
+        return
+    from porl_amd.agent.por import POR
+    dev1 = torch.device("cuda", 1)
+    torch.manual_seed(0)
+    a1 = POR(_args(60, 64, 2, B=32), 1000, 0.9, 10.0, device=dev1)
+    a0 = _make_por(60, 64, 2, 32)
+    rows = make_rows(32, 60, 2, seed=1)
+    s, r, sp, d, a = split_rows(torch.from_numpy(rows).to(DEV), 60, 2)
+    s1, r1, sp1, d1, _ = split_rows(torch.from_numpy(rows).to(dev1), 60, 2)
+    assert torch.cuda.current_device() == 0
+    assert a1.por_residual_update(s1, sp1, r1, d1) == a0.por_residual_update(s, sp, r, d)
