@@ -282,6 +282,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="issue every update back to back on one stream (profiling: kernels never overlap)")
     a = ap.parse_args()
     if a.workload == "cql":
         return bench_cql(a)
@@ -329,6 +331,7 @@ def main():
     torch.manual_seed(0)                                       # identical replicas on every rank
     agent = POR(args, max_steps=1000, tau=0.9, alpha=10.0, device=dev)
     agent.async_losses = True                                  # no host sync inside the loop
+    agent.pipeline = not a.no_pipeline
     losses = torch.zeros(a.steps + a.warmup, 8, device=dev)    # device-side loss history, one row per update
 
     def one_step(i):
@@ -370,12 +373,17 @@ def main():
 
     roof = None
     if not a.no_roofline:
-        # second pass, instrumented: HIP events around every kernel launch on the launch stream
+        # second pass, instrumented: HIP events around every kernel launch on the launch stream.  The timed loop above
+        # overlaps the policy phase with the next value phase on two streams; a kernel's roofline is quoted with the
+        # kernel ALONE on the chip, so this pass runs the same updates back to back on one stream.
+        agent.flush()
+        agent.pipeline = False
         E.prof_enable(True)
         for i in range(a.steps):
             one_step(a.warmup + i)
         prof = E.prof_read()
         E.prof_enable(False)
+        agent.pipeline = not a.no_pipeline
         # profile labels are "<launch of the step>:<kernel>"; the roofline is quoted per KERNEL (all its launches)
         by_kernel = {}
         for p in prof:

@@ -150,6 +150,10 @@ int porl_iql_value_apply(porl_iql* h, const porl_iql_hyper* hp, void* stream);
 /* optional, before porl_iql_policy_backward on the same batch: the policy MLP's forward (independent of the value
  * networks), e.g. while the value-gradient all-reduce is in flight; policy_backward then skips it */
 int porl_iql_policy_prefetch(porl_iql* h, void* stream);
+/* optional: the forward half of porl_iql_policy_backward on its own — second twin forward, policy forward, weights,
+ * NLL and dL/dmean, i.e. every read of the VALUE parameters the policy phase makes.  A pipelined caller records its
+ * "value parameters may change again" event right after it; porl_iql_policy_backward then only runs the rest. */
+int porl_iql_policy_forward(porl_iql* h, const porl_iql_hyper* hp, void* stream);
 int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream);
 /* por.py:109 — Adam on the policy (lr = hp->policy_lr). */
 int porl_iql_policy_apply(porl_iql* h, const porl_iql_hyper* hp, void* stream);

@@ -19,7 +19,7 @@ SYMBOLS = [
     "porl_iql_create", "porl_iql_destroy", "porl_iql_group_floats", "porl_iql_group_tensors",
     "porl_iql_tensor_info", "porl_iql_workspace_floats", "porl_iql_bind", "porl_iql_load_batch",
     "porl_iql_load_batch_sampled", "porl_iql_set_stats", "porl_iql_set_mode",
-    "porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_backward",
+    "porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_forward", "porl_iql_policy_backward",
     "porl_iql_policy_apply", "porl_iql_step", "porl_iql_policy_prefetch", "porl_iql_forward_value", "porl_iql_forward_policy",
     "porl_gemm_f32", "porl_adam_ema", "porl_gather_rows", "porl_sample_indices", "porl_epoch_indices", "porl_per_update", "porl_per_sample",
     "porl_prof_enable", "porl_prof_read", "porl_tune_set", "porl_tune_set_ptr", "porl_state2costmap",
@@ -108,7 +108,7 @@ def _declare(lib):
     lib.porl_iql_load_batch_sampled.argtypes = [vp, i32, vp, i64, i64, i32, i32, C.c_uint64, C.c_uint64, vp, vp]
     lib.porl_iql_set_stats.argtypes = [vp, vp]
     lib.porl_iql_set_mode.argtypes = [vp, i32]
-    for name in ("porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_backward",
+    for name in ("porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_forward", "porl_iql_policy_backward",
                  "porl_iql_policy_apply", "porl_iql_step"):
         getattr(lib, name).argtypes = [vp, C.POINTER(IqlHyper), vp]
     lib.porl_iql_policy_prefetch.argtypes = [vp, vp]

@@ -107,6 +107,7 @@ class IqlAgentBase(nn.Module):
     """Owns the engine; subclasses set the module attribute names the reference uses."""
 
     _warned_nll = False
+    pipeline = True     # async_losses mode only: overlap the policy phase with the next update's value phase
 
     def _setup_engine(self, vf: nn.Module, v_target: nn.Module, policy: nn.Module, *, obs_dim, pol_out_dim,
                       hidden_dim, n_hidden, layer_norm, pol_tanh, weight_mode, device, max_batch):
@@ -178,11 +179,13 @@ class IqlAgentBase(nn.Module):
         all-reduce and most of the value-group one overlap with the other phase's kernels."""
         eng, ex = self._engine, self._exchange
         world = ex.world_size
-        pipelined = self.async_losses
+        pipelined = self.async_losses and self.pipeline
         if not pipelined:
             eng.join()
         eng._ensure_bound()
         eng.set_mode((IqlEngine.MODE_TWO_SLOTS if pipelined else 0) | (IqlEngine.MODE_FOLD_COMBINE if world == 1 else 0))
+        if pipelined:
+            eng.wait_slot_free()               # the policy phase of two updates ago used the staging slot loaded next
         if replay is not None:
             B = eng.load_batch_sampled(replay.rows, batch, replay.seed, replay.draws, replay.act_dim,
                                        self._engine.cfg.weight_mode == 1)
@@ -201,22 +204,26 @@ class IqlAgentBase(nn.Module):
         eng.value_backward(hp)
         if world > 1:
             ex.allreduce_sum_(eng.grads_vf)
-        eng.join()                             # policy phase of the PREVIOUS update has read the old value nets
+        eng.wait_values_read()                 # the PREVIOUS update's policy phase has read the old value nets
         eng.value_apply(hp)
         # ---- policy phase -------------------------------------------------------------------------------------------
         if pipelined:
             main, side = torch.cuda.current_stream(eng.device), eng.side_stream()
-            k = (v_opt.step_count & 1) * 2
-            ev_v, ev_p = eng.event(k), eng.event(k + 1)
+            k = (v_opt.step_count & 1) * 3
+            ev_v, ev_f, ev_p = eng.event(k), eng.event(k + 1), eng.event(k + 2)
             ev_v.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ev_v)
+                eng.policy_forward(hp)                    # every read of the value nets the policy phase makes
+                ev_f.record(side)
                 eng.policy_backward(hp)
                 if world > 1:
                     ex.allreduce_sum_(eng.grads_pol)      # loss statistics stay per-rank shares in this mode
                 eng.policy_apply(hp)
                 ev_p.record(side)
-            eng._policy_done = ev_p
+            # the next value Adam waits for ev_f only; readers of the agent (flush) wait for ev_p
+            eng._values_read, eng._policy_done = ev_f, ev_p
+            eng._slot_users = (eng._slot_users[1], ev_p)
         else:
             eng.policy_backward(hp)
             ex.allreduce_sum_(eng.grads_pol)

@@ -231,12 +231,24 @@ struct ReduceArgs { int njobs; ReduceJob job[MAX_REDUCE_JOBS]; };
 __device__ __forceinline__ float reduce_chunk(const ReduceJob& j, long i0, float (*sh)[33]) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const long i = i0 + tx;
-  float s = j.op ? INFINITY : 0.f;
-  if (i < j.n)
-    for (int k = ty; k < j.nslab; k += 8) {
-      const float x = j.slab[(long)k * j.stride + i];
-      s = j.op ? fminf(s, x) : s + x;
+  // lane ty takes slabs ty, ty+8, ...: four interleaved running values (4 loads in flight), folded in a fixed order
+  const float id = j.op ? INFINITY : 0.f;
+  float s0 = id, s1 = id, s2 = id, s3 = id;
+  if (i < j.n) {
+    const float* p = j.slab + i;
+    int k = ty;
+    for (; k + 24 < j.nslab; k += 32) {
+      const float x0 = p[(long)k * j.stride], x1 = p[(long)(k + 8) * j.stride];
+      const float x2 = p[(long)(k + 16) * j.stride], x3 = p[(long)(k + 24) * j.stride];
+      if (j.op) { s0 = fminf(s0, x0); s1 = fminf(s1, x1); s2 = fminf(s2, x2); s3 = fminf(s3, x3); }
+      else { s0 += x0; s1 += x1; s2 += x2; s3 += x3; }
     }
+    for (; k < j.nslab; k += 8) {
+      const float x = p[(long)k * j.stride];
+      s0 = j.op ? fminf(s0, x) : s0 + x;
+    }
+  }
+  const float s = j.op ? fminf(fminf(s0, s1), fminf(s2, s3)) : (s0 + s1) + (s2 + s3);
   sh[ty][tx] = s;
   __syncthreads();
   float t = 0.f;
@@ -285,7 +297,8 @@ struct AdamArgs {
   float* p; float* g; float* m; float* v; float* tgt;
   long n4;              // float4 in the group
   long span4;           // float4 per sweep block (contiguous)
-  int sweep_blocks;     // blocks [0, sweep_blocks) sweep, the rest are reduce blocks
+  int reduce_blocks;    // blocks [0, reduce_blocks) run reduce jobs (dispatched first: their load chains are the
+                        // longest), the rest sweep
   AdamScalars s;
   int nregions; AdamRegion region[MAX_ADAM_REGIONS];
   int nskip; long skip_lo[MAX_REDUCE_JOBS], skip_hi[MAX_REDUCE_JOBS];   // float ranges owned by reduce blocks
@@ -302,9 +315,9 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
 __global__ __launch_bounds__(256) void adam_ema_kernel(const AdamArgs a) {
   __shared__ float sh[8][33];
   const AdamScalars s = a.s;
-  if ((int)blockIdx.x >= a.sweep_blocks) {
+  if ((int)blockIdx.x < a.reduce_blocks) {
     // ---- reduce block: one 32-output chunk of one job, then Adam on those outputs --------------------------
-    const int rb = blockIdx.x - a.sweep_blocks;
+    const int rb = blockIdx.x;
     int ji = 0;
 #pragma unroll
     for (int q = 1; q < MAX_REDUCE_JOBS; ++q)
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(const AdamArgs a) {
   float4* m4 = reinterpret_cast<float4*>(a.m);
   float4* v4 = reinterpret_cast<float4*>(a.v);
   float4* t4 = reinterpret_cast<float4*>(a.tgt);
-  const long lo4 = (long)blockIdx.x * a.span4, hi4 = min(a.n4, lo4 + a.span4);
+  const long lo4 = (long)(blockIdx.x - a.reduce_blocks) * a.span4, hi4 = min(a.n4, lo4 + a.span4);
   // block-uniform: does this span touch a slab region or a range owned by reduce blocks at all?
   bool special = false;
   for (int q = 0; q < a.nregions; ++q) special = special || (lo4 * 4 < a.region[q].hi && hi4 * 4 > a.region[q].lo);
@@ -378,6 +391,68 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(const AdamArgs a) {
       tt.z = tt.z * s.omeb + s.ema_beta * pp.z; tt.w = tt.w * s.omeb + s.ema_beta * pp.w;
       t4[i] = tt;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Small-batch Linear (+bias, +ReLU/tanh): the inference path (SORL.select_action, GaussianPolicy.act, TwinV.both
+// on a handful of states; reference agent/sorl.py:71-76, agent/policy.py:30-33).  At B <= SMALL_FWD_MAX_B a layer is
+// a GEMV bound by reading W once: one wave per output row, 16-byte loads of the row, the B inputs staged in LDS,
+// wave-shuffle reduction.  blockIdx.y selects one of up to 2 networks (the twins).  3 launches per 2-hidden-layer MLP
+// instead of pack + 2 grouped GEMMs + split-K mean + finish.
+// ---------------------------------------------------------------------------------------------------
+constexpr int SMALL_FWD_MAX_B = 8;
+struct SmallFwdArgs {
+  const float* W[2]; const float* bias[2];    // (N, K) row-major, (N)
+  const float* X[2]; long ldx[2];             // (B, K) inputs, row stride in floats
+  float* Y[2]; long ldy[2];                   // (B, N) outputs
+  int N, K, B, act;
+};
+
+__global__ __launch_bounds__(256) void small_fwd_kernel(const SmallFwdArgs a) {
+  extern __shared__ float xs[];               // B * K
+  const int net = blockIdx.y;
+  const float* __restrict__ X = a.X[net];
+  for (int i = threadIdx.x; i < a.B * a.K; i += 256) {
+    const int b = i / a.K, k = i - b * a.K;
+    xs[i] = X[(long)b * a.ldx[net] + k];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* __restrict__ W = a.W[net];
+  const bool vec = (a.K & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+  for (int n = blockIdx.x * 4 + wave; n < a.N; n += gridDim.x * 4) {
+    const float* __restrict__ w = W + (size_t)n * a.K;
+    float acc[SMALL_FWD_MAX_B];
+#pragma unroll
+    for (int b = 0; b < SMALL_FWD_MAX_B; ++b) acc[b] = 0.f;
+    if (vec) {
+      for (int k = lane * 4; k < a.K; k += 256) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + k);
+#pragma unroll
+        for (int b = 0; b < SMALL_FWD_MAX_B; ++b)
+          if (b < a.B) {
+            const float4 xv = *reinterpret_cast<const float4*>(xs + b * a.K + k);
+            acc[b] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[b]))));
+          }
+      }
+    } else {
+      for (int k = lane; k < a.K; k += 64) {
+        const float wv = w[k];
+#pragma unroll
+        for (int b = 0; b < SMALL_FWD_MAX_B; ++b)
+          if (b < a.B) acc[b] = fmaf(wv, xs[b * a.K + k], acc[b]);
+      }
+    }
+    const float bv = a.bias[net] ? a.bias[net][n] : 0.f;
+#pragma unroll
+    for (int b = 0; b < SMALL_FWD_MAX_B; ++b)
+      if (b < a.B) {
+        float v = wave_sum(acc[b]) + bv;
+        if (a.act == 1) v = fmaxf(v, 0.f);
+        else if (a.act == 2) v = tanhf(v);
+        if (lane == 0) a.Y[net][(long)b * a.ldy[net] + n] = v;
+      }
   }
 }
 

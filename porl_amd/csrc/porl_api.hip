@@ -182,6 +182,7 @@ struct porl_iql {
   int batch = 0;
   bool have_pol_target = false;
   bool pol_prefetched = false;      // porl_iql_policy_prefetch ran for the loaded batch: policy forward is done
+  bool pol_fwd_done = false;        // porl_iql_policy_forward ran for the loaded batch
   int pol_nslab = 1;
   int Sp = 0, Dp = 0, Hp = 0, parts_max = 0;
   Workspace ws{};
@@ -445,6 +446,7 @@ int porl_iql_load_batch(porl_iql* h, int32_t batch, const float* obs, int64_t ob
   if (pol_target) job(pol_target, pt_rs, W + h->ws.xt_slot[h->slot], h->cfg.pol_out_dim, h->Dp);
   h->have_pol_target = pol_target != nullptr;
   h->pol_prefetched = false;
+  h->pol_fwd_done = false;
   const long n = (long)batch * std::max(h->Sp, h->Dp);
   dim3 grid((unsigned)std::min<long>((n + 255) / 256, 1024), a.njobs);
   hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -557,6 +559,7 @@ int porl_iql_load_batch_sampled(porl_iql* h, int32_t batch, const float* rows, i
   h->batch = batch;
   h->have_pol_target = true;
   h->pol_prefetched = false;
+  h->pol_fwd_done = false;
   return PORL_OK;
 }
 
@@ -724,8 +727,10 @@ static int adam_launch(float* p, float* g, float* m, float* v, float* tgt, int64
   a.s.omb1 = (float)(1.0 - b1); a.s.beta2 = (float)b2; a.s.omb2 = (float)(1.0 - b2);
   a.s.eps = (float)eps; a.s.ema_beta = (float)ema_beta; a.s.omeb = (float)(1.0 - ema_beta);
   a.n4 = n / 4;
-  a.sweep_blocks = (int)std::min<long>((a.n4 + 255) / 256, 2048);
-  a.span4 = (a.n4 + a.sweep_blocks - 1) / a.sweep_blocks;
+  // one float4 per thread and a single trip through the block's loop whenever the grid allows it: a second, nearly
+  // empty trip would double every block's memory round trips (measured: 12 -> 19 us on the 80 MB value group)
+  const int sweep_blocks = (int)std::min<long>((a.n4 + 255) / 256, 1 << 20);
+  a.span4 = ((a.n4 + sweep_blocks - 1) / sweep_blocks + 255) / 256 * 256;
   int reduce_blocks = 0;
   double extra_bytes = 0.0;
   if (fin) {
@@ -755,7 +760,8 @@ static int adam_launch(float* p, float* g, float* m, float* v, float* tgt, int64
     a.job_block0[a.r.njobs] = reduce_blocks;
   }
   ProfScope ps("adam_ema_kernel", s, 0.0, (double)n * (tgt ? 36.0 : 28.0) + extra_bytes);
-  hipLaunchKernelGGL(adam_ema_kernel, dim3(a.sweep_blocks + reduce_blocks), dim3(256), 0, s, a);
+  a.reduce_blocks = reduce_blocks;
+  hipLaunchKernelGGL(adam_ema_kernel, dim3(sweep_blocks + reduce_blocks), dim3(256), 0, s, a);
   PORL_HIP(hipGetLastError());
   return PORL_OK;
 }
@@ -828,7 +834,10 @@ int porl_iql_policy_prefetch(porl_iql* h, void* stream) {
   return PORL_OK;
 }
 
-static int policy_backward_impl(porl_iql* h, const porl_iql_hyper* hp, hipStream_t s, ReduceArgs* defer) {
+// part: 1 = forward half only (second twin forward, policy forward, mean, weights + NLL + dL/dmean: everything of the
+// policy phase that reads the VALUE parameters), 2 = gradient half only (needs the forward half of the same batch),
+// 3 = both.
+static int policy_backward_impl(porl_iql* h, const porl_iql_hyper* hp, hipStream_t s, ReduceArgs* defer, int part = 3) {
   if (!h->have_pol_target) PORL_FAIL(PORL_ERR_INVALID, "policy step needs pol_target in porl_iql_load_batch");
   const int B = h->batch, S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden, D = h->cfg.pol_out_dim;
   const int Hp = h->Hp, Dp = h->Dp;
@@ -840,8 +849,11 @@ static int policy_backward_impl(porl_iql* h, const porl_iql_hyper* hp, hipStream
   int parts = 0;
   const bool LN = h->cfg.layer_norm != 0;
 
+  const int nblk = cdiv(B, NLL_ROWS_PER_BLOCK);
+  if (part == 2 && !h->pol_fwd_done) PORL_FAIL(PORL_ERR_INVALID, "porl_iql_policy_forward has not run for this batch");
+  if ((part & 1) && !h->pol_fwd_done) {
   // -- forward: updated twins (head only) + policy hidden layers, 3 nets per launch; the policy net is left out
-  //    when porl_iql_policy_prefetch already ran it for this batch (data-parallel mode) ----------------------
+  //    when porl_iql_policy_prefetch already ran it for this batch ---------------------------------------------
   const bool pre = h->pol_prefetched;
   h->pol_prefetched = false;
   for (int l = 0; l < L; ++l) {
@@ -871,7 +883,6 @@ static int policy_backward_impl(porl_iql* h, const porl_iql_hyper* hp, hipStream
   g_phase = "P4.";
 
   // -- advantage weights, NLL, dL/dmean, dL/dlog_std --------------------------------------------------
-  const int nblk = cdiv(B, NLL_ROWS_PER_BLOCK);
   {
     PolicyNllArgs a{};
     for (int i = 0; i < 2; ++i) { a.hp_v[i] = W + ws.hp_q[i]; a.b_v[i] = Pv + h->v[i].b[L]; }
@@ -886,6 +897,11 @@ static int policy_backward_impl(porl_iql* h, const porl_iql_hyper* hp, hipStream
     hipLaunchKernelGGL(policy_nll_kernel, dim3(nblk), dim3(256), 0, s, a);
     PORL_HIP(hipGetLastError());
   }
+  g_phase = "";
+  h->pol_fwd_done = true;
+  }
+  if (!(part & 2)) return PORL_OK;
+  h->pol_fwd_done = false;
 
   // -- backward ---------------------------------------------------------------------------------------
   ReduceArgs red{};
@@ -952,6 +968,12 @@ static int policy_backward_impl(porl_iql* h, const porl_iql_hyper* hp, hipStream
   return PORL_OK;
 }
 
+int porl_iql_policy_forward(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
+  PORL_TRY(check_ready(h, true)); DevGuard _dg(h->device);
+  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+  return policy_backward_impl(h, hp, (hipStream_t)stream, nullptr, 1);
+}
+
 int porl_iql_policy_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
   PORL_TRY(check_ready(h, true)); DevGuard _dg(h->device);
   if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
@@ -996,11 +1018,46 @@ static int pack_x(porl_iql* h, const float* x, int64_t x_rs, int batch, int64_t 
   return PORL_OK;
 }
 
+// One Linear layer of up to 2 networks on a handful of rows (kernels.hpp: small_fwd_kernel).
+static int small_fwd(int nnets, const float* const* Wt, const float* const* bias, const float* const* X, const long* ldx,
+                     float* const* Y, const long* ldy, int N, int K, int B, int act, hipStream_t s) {
+  SmallFwdArgs a{};
+  for (int i = 0; i < nnets; ++i) { a.W[i] = Wt[i]; a.bias[i] = bias[i]; a.X[i] = X[i]; a.ldx[i] = ldx[i]; a.Y[i] = Y[i]; a.ldy[i] = ldy[i]; }
+  a.N = N; a.K = K; a.B = B; a.act = act;
+  const size_t lds = sizeof(float) * (size_t)B * K;
+  if (lds > 64 * 1024) PORL_FAIL(PORL_ERR_UNSUPPORTED, "small-batch path: B*K too large");
+  ProfScope ps("small_fwd_kernel", s, 2.0 * nnets * B * N * K, 4.0 * nnets * ((double)N * K + B * (N + K)));
+  hipLaunchKernelGGL(small_fwd_kernel, dim3(std::min(cdiv(N, 4), 1024), nnets), dim3(256), lds, s, a);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
 int porl_iql_forward_value(porl_iql* h, int which, const float* x, int64_t x_rs, int32_t batch, float* v1_out,
                            float* v2_out, void* stream) {
   PORL_TRY(check_ready(h, false)); DevGuard _dg(h->device);
   if (!v1_out || !v2_out) PORL_FAIL(PORL_ERR_INVALID, "null output");
   hipStream_t s = (hipStream_t)stream;
+  if (batch >= 1 && batch <= SMALL_FWD_MAX_B && !h->cfg.layer_norm && x) {
+    // inference-sized batch: 3 GEMV launches straight from the caller's rows (no staging copy, no split-K)
+    const int S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden;
+    float* W = h->buf.workspace;
+    const float* P = which ? h->buf.params_tgt : h->buf.params_vf;
+    const float* in[2] = {x, x};
+    long ldin[2] = {(long)x_rs, (long)x_rs};
+    for (int l = 0; l <= L; ++l) {
+      const float* Wt[2] = {P + h->v[0].w[l], P + h->v[1].w[l]};
+      const float* bs[2] = {P + h->v[0].b[l], P + h->v[1].b[l]};
+      float* out[2];
+      long ldo[2];
+      for (int i = 0; i < 2; ++i) {
+        out[i] = l == L ? (i ? v2_out : v1_out) : W + h->ws.act_t[i][l & 1];
+        ldo[i] = l == L ? 1 : h->Hp;
+      }
+      PORL_TRY(small_fwd(2, Wt, bs, in, ldin, out, ldo, l == L ? 1 : H, l == 0 ? S : H, batch, l == L ? ACT_NONE : ACT_RELU, s));
+      for (int i = 0; i < 2; ++i) { in[i] = out[i]; ldin[i] = ldo[i]; }
+    }
+    return PORL_OK;
+  }
   // uses the s' staging buffer and the target scratch activations; invalidates a loaded minibatch
   PORL_TRY(pack_x(h, x, x_rs, batch, h->ws.xn, s));
   h->batch = 0;
@@ -1033,6 +1090,25 @@ int porl_iql_forward_policy(porl_iql* h, const float* x, int64_t x_rs, int32_t b
   PORL_TRY(check_ready(h, false)); DevGuard _dg(h->device);
   if (!mean_out) PORL_FAIL(PORL_ERR_INVALID, "null output");
   hipStream_t s = (hipStream_t)stream;
+  if (batch >= 1 && batch <= SMALL_FWD_MAX_B && x) {
+    const int S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden, D = h->cfg.pol_out_dim;
+    float* W = h->buf.workspace;
+    const float* P = h->buf.params_pol;
+    const float* in[1] = {x};
+    long ldin[1] = {(long)x_rs};
+    for (int l = 0; l <= L; ++l) {
+      const float* Wt[1] = {P + h->pol.w[l]};
+      const float* bs[1] = {P + h->pol.b[l]};
+      // hidden activations go to the TARGET-net scratch: the policy-phase buffers may still be in use by a pipelined
+      // update on another stream, the value-phase scratch is ordered on the caller's stream
+      float* out[1] = {l == L ? mean_out : W + h->ws.act_t[0][l & 1]};
+      long ldo[1] = {l == L ? (long)mean_rs : (long)h->Hp};
+      const int act = l < L ? ACT_RELU : (h->cfg.pol_tanh ? ACT_TANH : ACT_NONE);
+      PORL_TRY(small_fwd(1, Wt, bs, in, ldin, out, ldo, l == L ? D : H, l == 0 ? S : H, batch, act, s));
+      in[0] = out[0]; ldin[0] = ldo[0];
+    }
+    return PORL_OK;
+  }
   PORL_TRY(pack_x(h, x, x_rs, batch, h->ws.xn, s));
   h->batch = 0;
   const int S = h->cfg.obs_dim, H = h->cfg.hidden_dim, L = h->cfg.n_hidden, D = h->cfg.pol_out_dim;

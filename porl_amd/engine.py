@@ -44,13 +44,16 @@ class IqlEngine:
         # of update t+1 runs on the caller's stream; `_policy_done` is the event the side stream recorded last
         self._side = None
         self._policy_done = None
+        self._values_read = None
+        self._slot_users = (None, None)     # policy-done events of the last two pipelined updates (oldest first)
         self._events = []
         self._alloc()
 
     # -- streams -----------------------------------------------------------------------------------
     def side_stream(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            import os
+            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("PORL_SIDE_PRIORITY", "0")))
         return self._side
 
     def event(self, i):
@@ -61,7 +64,22 @@ class IqlEngine:
 
     def join(self):
         """Order the current stream behind an outstanding policy phase on the side stream (no host wait)."""
-        ev, self._policy_done = self._policy_done, None
+        ev, self._policy_done, self._values_read = self._policy_done, None, None
+        self._slot_users = (None, None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def wait_slot_free(self):
+        """Two staging slots alternate: the slot the next load writes was last read by the policy phase of two
+        pipelined updates ago."""
+        ev = self._slot_users[0]
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def wait_values_read(self):
+        """Order the current stream behind the forward half of the outstanding policy phase: after it the value
+        parameters may be overwritten (the rest of that phase only touches policy state and its own scratch)."""
+        ev, self._values_read = self._values_read, None
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
 
@@ -195,6 +213,7 @@ class IqlEngine:
 
     def value_backward(self, hp): self._phase("porl_iql_value_backward", hp)
     def value_apply(self, hp): self._phase("porl_iql_value_apply", hp)
+    def policy_forward(self, hp): self._phase("porl_iql_policy_forward", hp)
     def policy_backward(self, hp): self._phase("porl_iql_policy_backward", hp)
     def policy_apply(self, hp): self._phase("porl_iql_policy_apply", hp)
     def step(self, hp): self._phase("porl_iql_step", hp)

@@ -16,3 +16,11 @@ for S, H in ((362, 512), (60, 1024)):
     for _ in range(n): a = agent.select_action(x)
     el = time.perf_counter() - t0
     print(f"S={S} H={H}: select_action (B=1, returns numpy) {1e6 * el / n:.1f} us per call")
+    from porl_amd import engine as E
+    E.prof_enable(True)
+    for _ in range(200): agent.select_action(x)
+    prof = E.prof_read()
+    E.prof_enable(False)
+    dev_us = sum(p["total_ms"] for p in prof) * 1e3 / 200
+    print(f"    device time per call {dev_us:.1f} us in {sum(p['launches'] for p in prof) / 200:.0f} launches: "
+          + ", ".join(f"{p['name']} x{p['launches'] // 200}" for p in prof if p["launches"]))

@@ -388,3 +388,61 @@ def test_engine_on_a_non_current_device_guard():
     s1, r1, sp1, d1, _ = split_rows(torch.from_numpy(rows).to(dev1), 60, 2)
     assert torch.cuda.current_device() == 0
     assert a1.por_residual_update(s1, sp1, r1, d1) == a0.por_residual_update(s, sp, r, d)
+
+
+def test_checkpoint_roundtrip_through_torch_save(tmp_path):
+    """(f)2 checkpoint interchange: agent + BOTH optimizers + the LR scheduler go through torch.save / torch.load
+    (weights_only) into a freshly constructed agent, which must continue bit-identically with the original."""
+    S, A, B, H = 60, 2, 64, 128
+    rows = torch.from_numpy(make_rows(6 * B, S, A, seed=13)).to(DEV)
+    a = _make_por(S, H, 2, B)
+    for k in range(3):
+        s, r, sp, d, _ = split_rows(rows[k * B:(k + 1) * B], S, A)
+        a.por_residual_update(s, sp, r, d)
+    path = tmp_path / "ckpt.pt"
+    torch.save({"agent": a.state_dict(), "v_opt": a.v_optimizer.state_dict(),
+                "g_opt": a.goal_policy_optimizer.state_dict(), "sched": a.goal_lr_schedule.state_dict()}, path)
+    ck = torch.load(path, map_location=DEV, weights_only=True)
+    b = _make_por(S, H, 2, B, seed=77)                         # different init: everything must come from the file
+    b.load_state_dict(ck["agent"])
+    b.v_optimizer.load_state_dict(ck["v_opt"])
+    b.goal_policy_optimizer.load_state_dict(ck["g_opt"])
+    b.goal_lr_schedule.load_state_dict(ck["sched"])
+    assert b.goal_lr_schedule.get_last_lr() == a.goal_lr_schedule.get_last_lr()
+    for k in range(3, 6):
+        s, r, sp, d, _ = split_rows(rows[k * B:(k + 1) * B], S, A)
+        assert a.por_residual_update(s, sp, r, d) == b.por_residual_update(s, sp, r, d)
+    for (k1, v1), v2 in zip(a.state_dict().items(), b.state_dict().values()):
+        assert torch.equal(v1, v2), k1
+    sa, sb = a.v_optimizer.state_dict(), b.v_optimizer.state_dict()
+    for i in sa["state"]:
+        assert torch.equal(sa["state"][i]["exp_avg_sq"], sb["state"][i]["exp_avg_sq"])
+    # the optimizer file is torch.optim.Adam's format: a stock Adam over same-shaped parameters accepts it
+    stock = torch.optim.Adam([torch.nn.Parameter(torch.zeros_like(p)) for p in a.vf.parameters()], lr=1e-4)
+    stock.load_state_dict(ck["v_opt"])
+    assert stock.state_dict()["state"][0]["step"] == 3
+
+
+@pytest.mark.parametrize("B", [1, 3, 8])
+def test_small_batch_inference_path_matches_the_batched_kernels(B):
+    """(f)2 low-latency forward: at B <= 8 the policy mean and the twin values come from 3 GEMV launches
+    (small_fwd_kernel); same numbers as the training-size path (B = 9 rows go through the grouped GEMMs) and as the
+    oracle."""
+    from oracle.por_oracle import mlp_forward, twin_forward
+    agent = _make_por(60, 256, 2, 64)
+    o = PorOracle(_np_sd(agent), 60, 256, 2)
+    x9 = torch.from_numpy(make_rows(9, 60, 2, seed=3)[:, :60].copy()).to(DEV)
+    big = agent.goal_policy(x9).mean[:B]
+    small = agent.goal_policy(x9[:B]).mean
+    assert small.shape == (B, 60)
+    np.testing.assert_allclose(small.cpu().numpy(), big.cpu().numpy(), atol=2e-6)
+    ref, _ = mlp_forward(o.P, "goal_policy.net", x9[:B].cpu().numpy(), 2)
+    np.testing.assert_allclose(small.cpu().numpy(), ref, atol=2e-6)
+    v1, v2 = agent.vf.both(x9[:B])
+    r1, r2, _, _ = twin_forward(o.P, "vf", x9[:B].cpu().numpy(), 2, False)
+    np.testing.assert_allclose(v1.cpu().numpy(), r1, atol=2e-6)
+    np.testing.assert_allclose(v2.cpu().numpy(), r2, atol=2e-6)
+    # strided input rows (a column slice of a packed batch) are read in place
+    packed = torch.from_numpy(make_rows(B, 60, 2, seed=4)).to(DEV)
+    np.testing.assert_allclose(agent.goal_policy(packed[:, :60]).mean.cpu().numpy(),
+                               agent.goal_policy(packed[:, :60].contiguous()).mean.cpu().numpy(), atol=0)
