@@ -271,6 +271,9 @@ int porl_gemm_f32(int mode, int tile, int32_t M, int32_t N, int32_t K,
 int porl_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t n,
                   double lr, int32_t step, double beta1, double beta2, double eps, double ema_beta,
                   void* stream);
+/* util/util.py:54-56 on its own: target <- (1 - ema_beta) * target + ema_beta * source over n floats (n % 4 == 0).
+ * Same rounding as the sweep fused into porl_adam_ema. */
+int porl_ema(float* target, const float* source, int64_t n, double ema_beta, void* stream);
 
 /* out[i,:] = rows[idx[i],:] — minibatch gather from a device-resident packed-row replay store
  * (replaces the numpy fancy-index + H2D copies of ReplayBuffer.sample, buffer/replay_buffer.py:64-73). */

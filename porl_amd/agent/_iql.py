@@ -47,8 +47,18 @@ class ArenaAdam:
     def step(self):
         raise RuntimeError("ArenaAdam steps inside the fused update (por_residual_update / update)")
 
+    sharded = False     # set by the reduce-scatter exchange: each rank holds current moments for its slice only
+
+    def _gather_moments(self):
+        if self.sharded:
+            eng, ex = self._agent._engine, self._agent._exchange
+            _, _, m, v, _ = eng.group(self._group)
+            ex.all_gather_(m)
+            ex.all_gather_(v)
+
     def state_dict(self):
         self._agent.flush()
+        self._gather_moments()
         ms, vs = self._moments()
         state = {}
         if self.step_count > 0:
@@ -108,6 +118,10 @@ class IqlAgentBase(nn.Module):
 
     _warned_nll = False
     pipeline = True     # async_losses mode only: overlap the policy phase with the next update's value phase
+    # data-parallel exchange: "reduce_scatter" = reduce-scatter of the flat gradient group -> Adam on this rank's 1/N
+    # slice (N-fold less optimizer traffic) -> all-gather of the parameters (+ a local Polyak sweep for the target);
+    # "all_reduce" = SUM all-reduce of the whole group, Adam everywhere.  Same arithmetic per element.
+    grad_exchange = "reduce_scatter"
 
     def _setup_engine(self, vf: nn.Module, v_target: nn.Module, policy: nn.Module, *, obs_dim, pol_out_dim,
                       hidden_dim, n_hidden, layer_norm, pol_tanh, weight_mode, device, max_batch):
@@ -116,6 +130,7 @@ class IqlAgentBase(nn.Module):
         self._mods = (vf, v_target, policy)
         self._adopt(copy_from_modules=True)
         self._exchange = GradExchange()
+        self._gslice = {}
         self.async_losses = False     # True: return a (3,) device VIEW [v_loss, g_loss, min_nll], no host sync
 
     def _adopt(self, copy_from_modules=False):
@@ -202,10 +217,13 @@ class IqlAgentBase(nn.Module):
         # ---- value phase (current stream) -----------------------------------------------------------------------
         # replay sharded across ranks: each rank's gradients carry 1/B_global, so SUM == global mean
         eng.value_backward(hp)
-        if world > 1:
-            ex.allreduce_sum_(eng.grads_vf)
-        eng.wait_values_read()                 # the PREVIOUS update's policy phase has read the old value nets
-        eng.value_apply(hp)
+        if world > 1 and self._sharded():
+            self._sharded_apply(IqlEngine.GROUP_VF, hp, v_opt)
+        else:
+            if world > 1:
+                ex.allreduce_sum_(eng.grads_vf)
+            eng.wait_values_read()             # the PREVIOUS update's policy phase has read the old value nets
+            eng.value_apply(hp)
         # ---- policy phase -------------------------------------------------------------------------------------------
         if pipelined:
             main, side = torch.cuda.current_stream(eng.device), eng.side_stream()
@@ -217,20 +235,51 @@ class IqlAgentBase(nn.Module):
                 eng.policy_forward(hp)                    # every read of the value nets the policy phase makes
                 ev_f.record(side)
                 eng.policy_backward(hp)
-                if world > 1:
-                    ex.allreduce_sum_(eng.grads_pol)      # loss statistics stay per-rank shares in this mode
-                eng.policy_apply(hp)
+                if world > 1 and self._sharded():         # loss statistics stay per-rank shares in this mode
+                    self._sharded_apply(IqlEngine.GROUP_POL, hp, p_opt)
+                else:
+                    if world > 1:
+                        ex.allreduce_sum_(eng.grads_pol)
+                    eng.policy_apply(hp)
                 ev_p.record(side)
             # the next value Adam waits for ev_f only; readers of the agent (flush) wait for ev_p
             eng._values_read, eng._policy_done = ev_f, ev_p
             eng._slot_users = (eng._slot_users[1], ev_p)
         else:
             eng.policy_backward(hp)
-            ex.allreduce_sum_(eng.grads_pol)
-            eng.policy_apply(hp)
+            if self._sharded():
+                self._sharded_apply(IqlEngine.GROUP_POL, hp, p_opt)
+            else:
+                ex.allreduce_sum_(eng.grads_pol)
+                eng.policy_apply(hp)
             ex.allreduce_stats_(eng.stats)
         sched.step()
         return self._losses()
+
+    def _sharded(self):
+        eng, ex = self._engine, self._exchange
+        return self.grad_exchange == "reduce_scatter" and ex.can_shard(eng.grads_vf) and ex.can_shard(eng.grads_pol)
+
+    def _sharded_apply(self, group, hp, opt):
+        """reduce-scatter(SUM) of the group's gradients, torch-exact Adam on this rank's slice only,
+        all-gather of the updated parameters; the target network is then swept locally (Polyak) from the gathered
+        parameters.  Moments of the other slices are not kept here: ArenaAdam.state_dict() gathers them."""
+        from .. import engine as E
+        eng, ex = self._engine, self._exchange
+        p, g, m, v, tgt = eng.group(group)
+        gs = self._gslice.get(group)
+        if gs is None or gs.numel() != p.numel() // ex.world_size:
+            gs = self._gslice[group] = torch.empty(p.numel() // ex.world_size, dtype=torch.float32, device=p.device)
+        ex.reduce_scatter_sum(g, gs)
+        if group == IqlEngine.GROUP_VF:
+            eng.wait_values_read()             # the PREVIOUS update's policy phase has read the old value nets
+        b1, b2 = opt.param_groups[0]["betas"]
+        E.adam_ema(ex.slice_of(p), gs, ex.slice_of(m), ex.slice_of(v), None, opt.lr, opt.step_count, b1, b2,
+                   opt.param_groups[0]["eps"], 0.0)
+        ex.all_gather_(p)
+        if tgt is not None:
+            E.ema(tgt, p, hp.ema_beta)
+        opt.sharded = True
 
     def flush(self):
         """Join an outstanding policy phase (pipelined mode) into the current stream; a no-op otherwise.  Called by

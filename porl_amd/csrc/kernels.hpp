@@ -306,6 +306,10 @@ struct AdamArgs {
   ReduceArgs r;
 };
 
+// Polyak update of one element (util/util.py:54-56): target <- (1 - beta) * target + beta * source.  One definition
+// for the fused sweep and the stand-alone kernel, so both round the same way.
+__device__ __forceinline__ float ema1(float t, float p, float omeb, float ema_beta) { return t * omeb + ema_beta * p; }
+
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamScalars& s) {
   m = m + s.omb1 * (g - m);
   v = v * s.beta2 + s.omb2 * g * g;
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(const AdamArgs a) {
         float pp = a.p[e], mm = a.m[e], vv = a.v[e];
         adam1(pp, t, mm, vv, s);
         a.p[e] = pp; a.m[e] = mm; a.v[e] = vv;
-        if (a.tgt) a.tgt[e] = a.tgt[e] * s.omeb + s.ema_beta * pp;
+        if (a.tgt) a.tgt[e] = ema1(a.tgt[e], pp, s.omeb, s.ema_beta);
       }
     }
     return;
@@ -387,11 +391,26 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(const AdamArgs a) {
     p4[i] = pp; m4[i] = mm; v4[i] = vv;
     if (a.tgt) {
       float4 tt = t4[i];
-      tt.x = tt.x * s.omeb + s.ema_beta * pp.x; tt.y = tt.y * s.omeb + s.ema_beta * pp.y;
-      tt.z = tt.z * s.omeb + s.ema_beta * pp.z; tt.w = tt.w * s.omeb + s.ema_beta * pp.w;
+      tt.x = ema1(tt.x, pp.x, s.omeb, s.ema_beta); tt.y = ema1(tt.y, pp.y, s.omeb, s.ema_beta);
+      tt.z = ema1(tt.z, pp.z, s.omeb, s.ema_beta); tt.w = ema1(tt.w, pp.w, s.omeb, s.ema_beta);
       t4[i] = tt;
     }
   }
+}
+
+// Stand-alone Polyak sweep (12 B/param): the data-parallel path applies Adam to a 1/N slice per rank, all-gathers the
+// parameters and then updates the whole target locally — cheaper than gathering the target as well.
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ tgt, const float* __restrict__ src, long n4,
+                                                   float omeb, float ema_beta) {
+  float4* t4 = reinterpret_cast<float4*>(tgt);
+  const float4* p4 = reinterpret_cast<const float4*>(src);
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 tt = t4[i];
+  const float4 pp = p4[i];
+  tt.x = ema1(tt.x, pp.x, omeb, ema_beta); tt.y = ema1(tt.y, pp.y, omeb, ema_beta);
+  tt.z = ema1(tt.z, pp.z, omeb, ema_beta); tt.w = ema1(tt.w, pp.w, omeb, ema_beta);
+  t4[i] = tt;
 }
 
 // ---------------------------------------------------------------------------------------------------

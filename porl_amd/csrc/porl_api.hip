@@ -1171,6 +1171,19 @@ int porl_adam_ema(float* p, const float* g, float* m, float* v, float* target, i
   return adam_launch(p, const_cast<float*>(g), m, v, target, n, lr, step, beta1, beta2, eps, ema_beta, (hipStream_t)stream);
 }
 
+int porl_ema(float* target, const float* source, int64_t n, double ema_beta, void* stream) {
+  if (!target || !source || n < 0 || n % 4) PORL_FAIL(PORL_ERR_INVALID, "need buffers and a multiple of 4 floats");
+  if (!aligned16(target) || !aligned16(source)) PORL_FAIL(PORL_ERR_INVALID, "buffers must be 16-byte aligned");
+  if (n == 0) return PORL_OK;
+  DevGuard _dg(device_of(target));
+  const long n4 = n / 4;
+  ProfScope ps("ema_kernel", (hipStream_t)stream, 0.0, 12.0 * n);
+  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, target, source, n4,
+                     (float)(1.0 - ema_beta), (float)ema_beta);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
 int porl_gather_rows(const float* rows, int64_t row_stride, const int64_t* idx, int32_t n, int32_t width, float* out,
                      int64_t out_stride, void* stream) {
   if (!rows || !idx || !out || n < 0 || width < 1) PORL_FAIL(PORL_ERR_INVALID, "bad gather arguments");

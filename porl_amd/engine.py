@@ -89,9 +89,15 @@ class IqlEngine:
             self._mode = mode
 
     # -- memory ------------------------------------------------------------------------------------
+    # Flat groups are allocated a little longer than the C library needs (zero tail) so that they split into equal,
+    # 16-byte-aligned slices for every data-parallel world size that divides 840 (1..8, 10, 12, ...): the
+    # reduce-scatter / sharded Adam / all-gather exchange (agent/_iql.py) works on those slices.
+    SLICE_QUANTUM = 4 * 840
+
     def _alloc(self):
         dev = self.device
-        z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+        q = self.SLICE_QUANTUM
+        z = lambda n: torch.zeros((n + q - 1) // q * q, dtype=torch.float32, device=dev)
         self.params_vf, self.params_tgt, self.params_pol = z(self.n_vf), z(self.n_vf), z(self.n_pol)
         self.grads_vf, self.grads_pol = z(self.n_vf), z(self.n_pol)
         self.adam_m_vf, self.adam_v_vf = z(self.n_vf), z(self.n_vf)
@@ -182,6 +188,7 @@ class IqlEngine:
             N.ptr(rew), rew.stride(0), N.ptr(term), term.stride(0),
             N.ptr(pol_target), 0 if pol_target is None else pol_target.stride(0),
             N.current_stream_ptr(self.device)), "porl_iql_load_batch")
+        self.last_batch = B
         return B
 
     def load_batch_sampled(self, rows, batch, seed, step, act_dim, target_is_action, idx_out=None):
@@ -192,6 +199,7 @@ class IqlEngine:
         N.check(self._lib.porl_iql_load_batch_sampled(
             self._h, batch, N.ptr(rows), rows.stride(0), rows.shape[0], act_dim, int(target_is_action),
             seed & 0xFFFFFFFFFFFFFFFF, step, N.ptr(idx_out), N.current_stream_ptr(self.device)), "porl_iql_load_batch_sampled")
+        self.last_batch = batch
         return batch
 
     def set_stats(self, stats):
@@ -201,6 +209,12 @@ class IqlEngine:
             raise RuntimeError("stats must be >= 8 contiguous fp32 on the engine's device")
         N.check(self._lib.porl_iql_set_stats(self._h, N.ptr(stats)), "porl_iql_set_stats")
         self.stats = stats
+
+    def group(self, g):
+        """(params, grads, exp_avg, exp_avg_sq, target or None) flat tensors of optimizer group g."""
+        if g == self.GROUP_VF:
+            return self.params_vf, self.grads_vf, self.adam_m_vf, self.adam_v_vf, self.params_tgt
+        return self.params_pol, self.grads_pol, self.adam_m_pol, self.adam_v_pol, None
 
     def hyper(self, **kw):
         d = dict(tau=0.9, discount=0.99, alpha=10.0, ema_beta=0.005, inv_batch=1.0, value_lr=1e-4,
@@ -264,6 +278,10 @@ def gemm_f32(mode, A, B, M, N_, K, lda, ldb, C_out, ldc, bias=None, act=0, mask=
 def adam_ema(p, g, m, v, target, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, ema_beta=0.0):
     N.check(N.lib().porl_adam_ema(N.ptr(p), N.ptr(g), N.ptr(m), N.ptr(v), N.ptr(target), p.numel(), lr, step,
                                   beta1, beta2, eps, ema_beta, N.current_stream_ptr(p)), "porl_adam_ema")
+
+
+def ema(target, source, ema_beta):
+    N.check(N.lib().porl_ema(N.ptr(target), N.ptr(source), target.numel(), ema_beta, N.current_stream_ptr(target)), "porl_ema")
 
 
 def gather_rows(rows, idx, out=None):

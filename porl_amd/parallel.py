@@ -44,6 +44,28 @@ class GradExchange:
             return d.all_reduce(flat, op=d.ReduceOp.SUM, group=self.group, async_op=True)
         return None
 
+    def can_shard(self, flat: torch.Tensor):
+        """The flat group splits into equal 16-byte-aligned slices for this world size."""
+        w = self.world_size
+        return w > 1 and flat.numel() % (4 * w) == 0
+
+    def slice_of(self, flat: torch.Tensor):
+        w, r = self.world_size, self.rank
+        n = flat.numel() // w
+        return flat[r * n:(r + 1) * n]
+
+    def reduce_scatter_sum(self, flat: torch.Tensor, out: torch.Tensor):
+        """out (numel/world floats) <- this rank's slice of the SUM over ranks of `flat`."""
+        d = _dist()
+        d.reduce_scatter_tensor(out, flat, op=d.ReduceOp.SUM, group=self.group)
+        return out
+
+    def all_gather_(self, flat: torch.Tensor):
+        """Every rank contributes its own slice of `flat`; afterwards all of `flat` is current everywhere."""
+        d = _dist()
+        d.all_gather_into_tensor(flat, self.slice_of(flat), group=self.group)
+        return flat
+
     def allreduce_stats_(self, stats: torch.Tensor):
         """stats[0:2] = (v_loss, g_loss) shares -> SUM; stats[2] = min NLL -> MIN."""
         d = _dist()

@@ -32,7 +32,7 @@ def _agent(B):
                1000, 0.9, 10.0, device=torch.device("cuda"))
 
 
-def _worker(rank, world, port, out_dir, async_mode=False):
+def _worker(rank, world, port, out_dir, async_mode=False, exchange="reduce_scatter"):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
@@ -40,6 +40,7 @@ def _worker(rank, world, port, out_dir, async_mode=False):
     from porl_amd.util.synth import split_rows
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     agent = _agent(BL)
+    agent.grad_exchange = exchange
     agent.async_losses = async_mode                          # async: pipelined, policy phase + its exchange on the side stream
     rows = torch.from_numpy(_rows()).cuda()
     losses = []
@@ -51,18 +52,22 @@ def _worker(rank, world, port, out_dir, async_mode=False):
         losses.append(tuple(out[:2].tolist()) if async_mode else out)
     if async_mode:
         assert agent._engine._policy_done is not None        # the last policy phase is still on the side stream ...
-    if rank == 0:                                            # ... and state_dict() completes it
+    sd = agent.state_dict()                                  # ... and state_dict() completes it
+    osd = agent.v_optimizer.state_dict()                     # (collective in reduce_scatter mode: moments are gathered)
+    if rank == 0:
         np.savez(os.path.join(out_dir, "dp.npz"), losses=np.array(losses),
-                 **{k: v.cpu().numpy() for k, v in agent.state_dict().items()})
+                 adam_m0=osd["state"][0]["exp_avg"].cpu().numpy(), adam_v2=osd["state"][2]["exp_avg_sq"].cpu().numpy(),
+                 **{k: v.cpu().numpy() for k, v in sd.items()})
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["reduce_scatter", "all_reduce"])
 @pytest.mark.parametrize("async_mode", [False, True])
-def test_two_rank_update_equals_global_batch_update(tmp_path, async_mode):
+def test_two_rank_update_equals_global_batch_update(tmp_path, async_mode, exchange):
     from porl_amd.util.synth import split_rows
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), async_mode), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), async_mode, exchange), nprocs=world, join=True)
     got = np.load(tmp_path / "dp.npz")
     agent = _agent(world * BL)
     rows = torch.from_numpy(_rows()).cuda()
@@ -73,3 +78,6 @@ def test_two_rank_update_equals_global_batch_update(tmp_path, async_mode):
             np.testing.assert_allclose(got["losses"][k], loss, rtol=2e-6)
     for k, v in agent.state_dict().items():
         np.testing.assert_allclose(got[k], v.cpu().numpy(), atol=2e-6, err_msg=k)
+    osd = agent.v_optimizer.state_dict()
+    np.testing.assert_allclose(got["adam_m0"], osd["state"][0]["exp_avg"].cpu().numpy(), atol=1e-7, rtol=1e-4)
+    np.testing.assert_allclose(got["adam_v2"], osd["state"][2]["exp_avg_sq"].cpu().numpy(), atol=1e-10, rtol=1e-4)

@@ -76,7 +76,7 @@ def test_arena_adam_state_dict_format_roundtrip():
     from porl_amd.agent.por import POR
     a = POR(_args(8, 16, 1), 50, 0.9, 10.0)
     assert a.v_optimizer.state_dict()["state"] == {}
-    a._engine.adam_m_vf.copy_(torch.arange(a._engine.n_vf, dtype=torch.float32))
+    a._engine.adam_m_vf[:a._engine.n_vf].copy_(torch.arange(a._engine.n_vf, dtype=torch.float32))   # (flat groups carry a zero tail)
     a.v_optimizer.step_count = 7
     sd = a.v_optimizer.state_dict()
     names = [n for n, _ in a.vf.named_parameters()]
@@ -164,6 +164,60 @@ def test_dp_gradient_sum_equals_global_batch(tmp_path):
     np.testing.assert_allclose(got["flat"], ref, atol=1e-7, rtol=1e-5)
     np.testing.assert_allclose(got["stats"][0], v_loss, rtol=1e-6)
     assert got["stats"][2] == 0.0                       # MIN over ranks
+
+
+def _rs_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from oracle.por_oracle import AdamState, adam_step
+    from porl_amd.parallel import GradExchange
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ex = GradExchange()
+    n = 4 * world * 25
+    rng = np.random.default_rng(3)
+    p0 = rng.normal(size=n).astype(np.float32)
+    g_local = np.random.default_rng(10 + rank).normal(size=n).astype(np.float32)
+
+    def adam(p, g, st):                                   # the oracle's torch-exact Adam on a flat range
+        P = {"w": p}
+        adam_step(P, {"w": g}, st)
+        return P["w"]
+
+    # (a) all-reduce, Adam on everything
+    ga = torch.from_numpy(g_local.copy())
+    ex.allreduce_sum_(ga)
+    pa = adam(p0.copy(), ga.numpy(), AdamState(1e-3, ["w"]))
+    # (b) reduce-scatter, Adam on this rank's slice, all-gather of the parameters
+    gb, pb = torch.from_numpy(g_local.copy()), torch.from_numpy(p0.copy())
+    assert ex.can_shard(gb)
+    gs = torch.empty(n // world)
+    ex.reduce_scatter_sum(gb, gs)
+    sl = ex.slice_of(pb)
+    sl.copy_(torch.from_numpy(adam(sl.numpy().copy(), gs.numpy(), AdamState(1e-3, ["w"]))))
+    ex.all_gather_(pb)
+    assert np.array_equal(pb.numpy(), pa), "sharded Adam != all-reduce Adam"
+    assert not ex.can_shard(torch.zeros(4 * world + 4))       # slices must be equal and 16-byte aligned
+    if rank == 0:
+        np.save(os.path.join(out_dir, "rs_ok.npy"), pb.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_sharded_adam_all_gather_equals_all_reduce(tmp_path):
+    """SURVEY.md §5.8 exchange (GradExchange.reduce_scatter_sum / slice_of / all_gather_): bit-equal to the all-reduce
+    path, world_size 2 over gloo; the device version of the same sequence is tests/test_dp_gpu.py."""
+    mp.spawn(_rs_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "rs_ok.npy")
+
+
+def test_flat_groups_split_evenly_for_every_world_size_up_to_8():
+    from porl_amd.agent.por import POR
+    torch.manual_seed(0)
+    eng = POR(_args(60, 64, 2), 1000, 0.9, 10.0)._engine
+    for flat in (eng.params_vf, eng.grads_vf, eng.adam_m_vf, eng.params_tgt, eng.params_pol, eng.grads_pol):
+        assert all(flat.numel() % (4 * w) == 0 for w in range(1, 9))
+    assert eng.params_vf.numel() >= eng.n_vf and not eng.params_vf[eng.n_vf:].any()
 
 
 def test_pack_csv_dir_concatenates_the_reference_shard_format(tmp_path):
