@@ -81,3 +81,22 @@ def test_two_rank_update_equals_global_batch_update(tmp_path, async_mode, exchan
     osd = agent.v_optimizer.state_dict()
     np.testing.assert_allclose(got["adam_m0"], osd["state"][0]["exp_avg"].cpu().numpy(), atol=1e-7, rtol=1e-4)
     np.testing.assert_allclose(got["adam_v2"], osd["state"][2]["exp_avg_sq"].cpu().numpy(), atol=1e-10, rtol=1e-4)
+
+
+def test_bench_starts_its_own_ranks_from_the_bare_command():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (the driver's command form): the parent makes
+    no GPU call, starts N rank processes itself and relays rank 0's JSON line.  Rehearsed with gloo (two ranks on the
+    box's one GPU; RCCL needs a device per rank)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PORL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--rows-per-gpu", "20000", "--no-roofline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"] == "gloo"
+    assert out["config"]["global_batch"] == 2048 and out["scaling"] == "weak"
+    assert np.isfinite([out["value"], out["final_losses"]["v_loss"], out["final_losses"]["g_loss"]]).all()
