@@ -203,9 +203,14 @@ typedef struct porl_qnet_hyper {
 
 int porl_qnet_create(const porl_qnet_cfg* cfg, porl_qnet** out);
 void porl_qnet_destroy(porl_qnet* h);
+/* Flat parameter group = per Linear layer an IMAGE of round32(out) rows x (round16(in) + 4) floats with the (out, in)
+ * weight matrix in its top-left corner and zeros elsewhere, followed by round32(out) bias floats (zero padded): the
+ * step kernel stages a layer into LDS with one linear copy.  tensor_info gives, for tensor `index` (weights and
+ * biases alternate), its float offset, shape (rows == 0: a vector of `cols`) and the row stride of a weight matrix. */
 int64_t porl_qnet_param_floats(const porl_qnet* h);
 int32_t porl_qnet_tensors(const porl_qnet* h);
-int porl_qnet_tensor_info(const porl_qnet* h, int index, int64_t* offset, int32_t* rows, int32_t* cols);
+int porl_qnet_tensor_info(const porl_qnet* h, int index, int64_t* offset, int32_t* rows, int32_t* cols,
+                          int32_t* row_stride);
 int64_t porl_qnet_workspace_floats(const porl_qnet* h);
 int porl_qnet_bind(porl_qnet* h, const porl_qnet_buffers* bufs);
 /* The five tensors ReplayBuffer.sample returns (buffer/replay_buffer.py:53-75); *_rs = row / element
@@ -241,6 +246,14 @@ typedef struct porl_qnet_variant {
   const float* is_weights;
   const float* uniform_weight;
   float* td_abs;
+  /* BCQ (src/porl/policy/bcq.py:59-74): (batch, n_actions) fp32 0/1 mask of the actions the behaviour policy allows in
+   * s', row b for minibatch position b; the bootstrap action is argmax_a [Q_target(s',a) + (mask - 1) * 1e10] and is
+   * valued by Q_target.  NULL = off. */
+  const float* next_mask;
+  /* 1: drop the TD term; with hyper.alpha = 1 the loss is the cross-entropy of softmax(Q(s)) against the taken
+   * action minus ln(n_actions) — the behaviour-policy pre-training step of bcq.py:23-47 on a "Q" network that holds
+   * the behaviour policy's logits. */
+  int32_t td_off;
 } porl_qnet_variant;
 int porl_qnet_learn_variant(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions,
                             const float* rewards, const float* next_states, int64_t n_rs, const float* dones,
@@ -271,6 +284,11 @@ int porl_gemm_f32(int mode, int tile, int32_t M, int32_t N, int32_t K,
 int porl_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t n,
                   double lr, int32_t step, double beta1, double beta2, double eps, double ema_beta,
                   void* stream);
+/* F.softmax(logits, -1) > threshold as a 0/1 fp32 mask (src/porl/net/behavior_policy.py:41-55): logits (batch, ld)
+ * rows, n_actions <= 64 columns used; mask_out (batch, n_actions) dense. */
+int porl_softmax_mask(const float* logits, int64_t ld, int32_t batch, int32_t n_actions, float threshold, float* mask_out,
+                      void* stream);
+
 /* util/util.py:54-56 on its own: target <- (1 - ema_beta) * target + ema_beta * source over n floats (n % 4 == 0).
  * Same rounding as the sweep fused into porl_adam_ema. */
 int porl_ema(float* target, const float* source, int64_t n, double ema_beta, void* stream);

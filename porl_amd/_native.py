@@ -21,7 +21,7 @@ SYMBOLS = [
     "porl_iql_load_batch_sampled", "porl_iql_set_stats", "porl_iql_set_mode",
     "porl_iql_value_backward", "porl_iql_value_apply", "porl_iql_policy_forward", "porl_iql_policy_backward",
     "porl_iql_policy_apply", "porl_iql_step", "porl_iql_policy_prefetch", "porl_iql_forward_value", "porl_iql_forward_policy",
-    "porl_gemm_f32", "porl_adam_ema", "porl_ema", "porl_gather_rows", "porl_sample_indices", "porl_epoch_indices", "porl_per_update", "porl_per_sample",
+    "porl_gemm_f32", "porl_adam_ema", "porl_ema", "porl_softmax_mask", "porl_gather_rows", "porl_sample_indices", "porl_epoch_indices", "porl_per_update", "porl_per_sample",
     "porl_prof_enable", "porl_prof_read", "porl_tune_set", "porl_tune_set_ptr", "porl_state2costmap",
     "porl_qnet_create", "porl_qnet_destroy", "porl_qnet_param_floats", "porl_qnet_tensors",
     "porl_qnet_tensor_info", "porl_qnet_workspace_floats", "porl_qnet_bind", "porl_qnet_load_batch",
@@ -68,7 +68,7 @@ class QnetHyper(C.Structure):
 
 class QnetVariant(C.Structure):
     _fields_ = [("double_dqn", C.c_int32), ("is_weights", C.c_void_p), ("uniform_weight", C.c_void_p),
-                ("td_abs", C.c_void_p)]
+                ("td_abs", C.c_void_p), ("next_mask", C.c_void_p), ("td_off", C.c_int32)]
 
 
 class EncCfg(C.Structure):
@@ -118,6 +118,7 @@ def _declare(lib):
                                   vp, i32, C.c_int, vp, vp]
     lib.porl_adam_ema.argtypes = [vp, vp, vp, vp, vp, i64, f64, i32, f64, f64, f64, f64, vp]
     lib.porl_ema.argtypes = [vp, vp, i64, f64, vp]
+    lib.porl_softmax_mask.argtypes = [vp, i64, i32, i32, f32, vp, vp]
     lib.porl_gather_rows.argtypes = [vp, i64, vp, i32, i32, vp, i64, vp]
     lib.porl_sample_indices.argtypes = [i64, i32, C.c_uint64, C.c_uint64, i64, vp, vp]
     lib.porl_epoch_indices.argtypes = [i64, i64, i32, C.c_uint64, C.c_uint64, i64, vp, vp]
@@ -133,7 +134,7 @@ def _declare(lib):
     lib.porl_qnet_param_floats.restype = i64
     lib.porl_qnet_tensors.argtypes = [vp]
     lib.porl_qnet_tensors.restype = i32
-    lib.porl_qnet_tensor_info.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
+    lib.porl_qnet_tensor_info.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.porl_qnet_workspace_floats.argtypes = [vp]
     lib.porl_qnet_workspace_floats.restype = i64
     lib.porl_qnet_bind.argtypes = [vp, C.POINTER(QnetBuffers)]

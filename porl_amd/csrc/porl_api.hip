@@ -1184,6 +1184,17 @@ int porl_ema(float* target, const float* source, int64_t n, double ema_beta, voi
   return PORL_OK;
 }
 
+int porl_softmax_mask(const float* logits, int64_t ld, int32_t batch, int32_t n_actions, float threshold, float* mask_out,
+                      void* stream) {
+  if (!logits || !mask_out || batch < 1 || n_actions < 1 || n_actions > 64 || ld < n_actions)
+    PORL_FAIL(PORL_ERR_INVALID, "bad softmax-mask arguments");
+  DevGuard _dg(device_of(mask_out));
+  hipLaunchKernelGGL(softmax_mask_kernel, dim3(cdiv(batch, 256)), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, batch,
+                     n_actions, threshold, mask_out);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
 int porl_gather_rows(const float* rows, int64_t row_stride, const int64_t* idx, int32_t n, int32_t width, float* out,
                      int64_t out_stride, void* stream) {
   if (!rows || !idx || !out || n < 0 || width < 1) PORL_FAIL(PORL_ERR_INVALID, "bad gather arguments");
@@ -1328,6 +1339,7 @@ struct porl_qnet {
   int device = -1;
   int batch = 0;
   int Sp = 0, Ap = 0, ld[PORL_MAX_HIDDEN + 2] = {0};     // padded leading dims per layer output
+  int wld[PORL_MAX_HIDDEN + 1] = {0};                    // row stride of layer l's weight image (floats)
   struct {
     int64_t xs, xn, rew, done, actions;                  // actions: int64 stored in 2 floats each
     int64_t act[PORL_MAX_HIDDEN + 1], tmp[2], dz[2], slab, part_td, part_pen, fslab, total;
@@ -1338,6 +1350,7 @@ struct porl_qnet {
   int fused_lds_bytes = 0;
   int64_t fslab_stride = 0;
   bool fslab_clean = false;          // alignment gaps of the flat layout are never written: zeroed once
+  bool slab_clean = false;           // same for the split-K slabs of the multi-launch path
 };
 
 
@@ -1359,10 +1372,20 @@ int porl_qnet_create(const porl_qnet_cfg* c, porl_qnet** out) {
     m.dims[l + 1] = c->hidden[l];
   }
   m.dims[L + 1] = c->n_actions;
+  // Parameter layout = the image the one-launch step kernel parks in LDS (csrc/qnet_fused.hpp): layer l is
+  // round32(out) rows of (round16(in) + 4) floats — the (out, in) weights in the top-left corner, zeros elsewhere —
+  // directly followed by round32(out) bias floats.  A block stages a layer with one linear, fully coalesced copy:
+  // no per-element address arithmetic, no bounds selects.  Zeros stay zeros under Adam (their gradient is always 0).
   int64_t cur = 0;
   for (int l = 0; l <= L; ++l) {
-    m.w[l] = add_tensor(h->tensors, cur, m.dims[l + 1], m.dims[l]);
-    m.b[l] = add_tensor(h->tensors, cur, 0, m.dims[l + 1]);
+    const int rows = (m.dims[l + 1] + 31) & ~31;
+    h->wld[l] = ((m.dims[l] + 15) & ~15) + 4;
+    m.w[l] = cur;
+    h->tensors.push_back({cur, m.dims[l + 1], m.dims[l]});
+    cur += (int64_t)rows * h->wld[l];
+    m.b[l] = cur;
+    h->tensors.push_back({cur, 0, m.dims[l + 1]});
+    cur += rows;
   }
   h->n_params = cur;
   h->Sp = (int)ru4(c->state_dim);
@@ -1395,11 +1418,11 @@ int porl_qnet_create(const porl_qnet_cfg* c, porl_qnet** out) {
       }
       for (int l = 0; l <= L; ++l) {
         fa.w_off[l] = m.w[l]; fa.b_off[l] = m.b[l];
-        wmax = std::max(wmax, ((m.dims[l + 1] + 31) & ~31) * (((m.dims[l] + 15) & ~15) + 4));
+        wmax = std::max(wmax, ((m.dims[l + 1] + 31) & ~31) * (((m.dims[l] + 15) & ~15) + 4 + 1));   // image + bias row
       }
       fa.lds_tmp[0] = off; off += QF_ROWS * (maxw + 4);
       fa.lds_tmp[1] = off; off += QF_ROWS * (maxw + 4);
-      fa.lds_w = off; off += wmax + 32;
+      fa.lds_w = off; off += wmax;
       ok = off * (int)sizeof(float) <= QF_MAX_LDS_BYTES;
     }
     h->fused_ok = ok;
@@ -1415,11 +1438,12 @@ int porl_qnet_create(const porl_qnet_cfg* c, porl_qnet** out) {
 void porl_qnet_destroy(porl_qnet* h) { delete h; }
 int64_t porl_qnet_param_floats(const porl_qnet* h) { return h ? h->n_params : 0; }
 int32_t porl_qnet_tensors(const porl_qnet* h) { return h ? (int32_t)h->tensors.size() : 0; }
-int porl_qnet_tensor_info(const porl_qnet* h, int index, int64_t* offset, int32_t* rows, int32_t* cols) {
+int porl_qnet_tensor_info(const porl_qnet* h, int index, int64_t* offset, int32_t* rows, int32_t* cols, int32_t* row_stride) {
   if (!h || index < 0 || index >= (int)h->tensors.size()) PORL_FAIL(PORL_ERR_INVALID, "tensor index out of range");
   if (offset) *offset = h->tensors[index].off;
   if (rows) *rows = h->tensors[index].rows;
   if (cols) *cols = h->tensors[index].cols;
+  if (row_stride) *row_stride = h->tensors[index].rows ? h->wld[index / 2] : 1;
   return PORL_OK;
 }
 int64_t porl_qnet_workspace_floats(const porl_qnet* h) { return h ? h->ws.total : 0; }
@@ -1437,6 +1461,7 @@ int porl_qnet_bind(porl_qnet* h, const porl_qnet_buffers* b) {
   h->device = device_of(b->workspace);
   h->batch = 0;
   h->fslab_clean = false;
+  h->slab_clean = false;
   return PORL_OK;
 }
 
@@ -1488,7 +1513,7 @@ static int qnet_forward(porl_qnet* h, int nnets, const float* const* params, con
     for (int k = 0; k < nnets; ++k) {
       const float* in = l == 0 ? inputs[k] : dst[k][l - 1];
       const int ldin = l == 0 ? h->Sp : h->ld[l - 1];
-      GemmProb p = make_prob(GEMM_NT, in, ldin, params[k] + h->net.w[l], K, dst[k][l], h->ld[l], B, Nn, K);
+      GemmProb p = make_prob(GEMM_NT, in, ldin, params[k] + h->net.w[l], h->wld[l], dst[k][l], h->ld[l], B, Nn, K);
       p.bias = params[k] + h->net.b[l];
       p.act = l < L ? ACT_RELU : ACT_NONE;
       g.p[k] = p;
@@ -1515,7 +1540,10 @@ static int qnet_fused_backward(porl_qnet* h, const porl_qnet_hyper* hp, int B, c
   a.gamma = hp->gamma; a.alpha = hp->alpha; a.inv_batch = hp->inv_batch;
   a.log_A = (float)std::log((double)h->cfg.n_actions);
   a.stamps = g_qnet_stamps;
-  if (var) { a.double_dqn = var->double_dqn; a.is_w = var->is_weights; a.w_uniform = var->uniform_weight; a.td_abs = var->td_abs; }
+  if (var) {
+    a.double_dqn = var->double_dqn; a.is_w = var->is_weights; a.w_uniform = var->uniform_weight; a.td_abs = var->td_abs;
+    a.next_mask = var->next_mask; a.td_off = var->td_off;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     PORL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1593,20 +1621,24 @@ int porl_qnet_cql_backward(porl_qnet* h, const porl_qnet_hyper* hp, void* stream
     const float* in = l == 0 ? W + h->ws.xs : W + h->ws.act[l - 1];
     const int ldin = l == 0 ? h->Sp : h->ld[l - 1];
     GemmGroup g{};
-    g.p[g.nprob] = make_prob(GEMM_TN, dz, h->ld[l], in, ldin, G + h->net.w[l], in_d, out_d, in_d, B);
+    g.p[g.nprob] = make_prob(GEMM_TN, dz, h->ld[l], in, ldin, G + h->net.w[l], h->wld[l], out_d, in_d, B);
     g.p[g.nprob].colsum = G + h->net.b[l];
     GemmProb& wg = g.p[g.nprob++];
     float* dz_next = nullptr;
     if (l > 0) {
       dz_next = W + h->ws.dz[(l - 1) & 1];
-      GemmProb q = make_prob(GEMM_NN, dz, h->ld[l], h->buf.params + h->net.w[l], in_d, dz_next, h->ld[l - 1], B, in_d, out_d);
+      GemmProb q = make_prob(GEMM_NN, dz, h->ld[l], h->buf.params + h->net.w[l], h->wld[l], dz_next, h->ld[l - 1], B, in_d, out_d);
       q.mask = in; q.ldmask = ldin;
       g.p[g.nprob++] = q;
     }
     const int tile = TILE_64x64;
     const int sk = pick_splitk(out_d, in_d, B, 1, 64, 64);
     if (sk > 1) {
-      const int64_t per = (int64_t)out_d * in_d;
+      const int64_t per = (int64_t)out_d * h->wld[l];          // slabs have the padded row stride of the gradient image
+      if (!h->slab_clean) {                                    // their padding columns are never written: zero them once
+        PORL_HIP(hipMemsetAsync(W + h->ws.slab, 0, sizeof(float) * (size_t)SK_MAX * (h->n_params + 64), s));
+        h->slab_clean = true;
+      }
       if (red.njobs + 2 > 8) { PORL_TRY(launch_reduce(red, s)); red = ReduceArgs{}; }
       float* slabW = slab; slab += (int64_t)sk * per;
       float* slabC = slab; slab += (int64_t)sk * out_d;

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 namespace porl {
 
 constexpr int QF_ROWS = 32;          // minibatch rows per block = one MFMA tile
@@ -43,6 +45,11 @@ struct QnetFusedArgs {
   const float* is_w;                 // (B,) per-sample loss weights (importance sampling), or null
   const float* w_uniform;            // device scalar multiplying every sample's loss (null = 1)
   float* td_abs;                     // (B,) |Q(s)[a] - target| for the priority write-back, or null
+  // BCQ (src/porl/policy/bcq.py:50-86): the bootstrap action is argmax_a [Q_tgt(s', a) + (mask[b, a] - 1) * 1e10],
+  // valued by Q_tgt — mask (B, n_actions) fp32 0/1 by minibatch position, from the behaviour policy; null = off
+  const float* next_mask;
+  int td_off;                        // 1: no TD term at all (loss = alpha * penalty: the cross-entropy pre-training of
+                                     // the behaviour policy, bcq.py:23-47, is logsumexp(z) - z[a] = penalty + ln A)
   unsigned long long* stamps;        // diagnostics: shader-clock stamps of block 0 at the phase boundaries, or null
 };
 
@@ -92,54 +99,33 @@ __device__ __forceinline__ void qf_load_inputs(float* dst_n, float* dst_s, int l
   }
 }
 
-// One layer's weights (N, K) -> LDS [round32(N)][round4(K) + 4], zero padded, in two halves: qf_fetch_w requests
-// them into registers (16-byte loads when rows allow; QF_WREGS float4 per thread cover 128 x 128), qf_park_w
-// writes them to LDS.  The kernel fetches layer j+1 before it computes layer j, so the round trip to L2 hides
-// behind the MFMA work of the previous layer.
-constexpr int QF_WREGS = (QF_MAX_W * (QF_MAX_W + 4) / 4 + 255) / 256;      // 17
-__device__ __forceinline__ void qf_fetch_w(float4 (&v)[QF_WREGS], float& bias_reg, const float* W, const float* bias, int N,
-                                           int K, int t) {
-  const int ld4 = (qf_rk(K) + 4) >> 2, total4 = qf_r32(N) * ld4;
-  const float inv_ld4 = 1.0f / (float)ld4;
-  const bool vec = (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0);
-  // branch-free: every lane loads from a valid address and the result is selected afterwards — a branch around
-  // a load makes the compiler drain vmcnt at the join, which would serialise the 17 requests
-  const float bv = bias[t < N ? t : 0];
-  bias_reg = t < N ? bv : 0.f;                       // N <= 128 < 256 threads
-  if (vec) {
-#pragma unroll
-    for (int u = 0; u < QF_WREGS; ++u) {
-      if (u * 256 >= total4) continue;               // uniform: small layers use few slots
-      const int i = u * 256 + t;
-      const int n = qf_div(i, inv_ld4), k = (i - n * ld4) << 2;
-      const bool ok = i < total4 && n < N && k < K;
-      const float4 x = *reinterpret_cast<const float4*>(W + (ok ? n * K + k : 0));
-      v[u] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  } else {
-#pragma unroll
-    for (int u = 0; u < QF_WREGS; ++u) {
-      if (u * 256 >= total4) continue;
-      const int i = u * 256 + t;
-      const int n = qf_div(i, inv_ld4), k = (i - n * ld4) << 2;
-      const bool ok = i < total4 && n < N;
-      const float* p = W + (ok ? (long)n * K : 0L);
-      const float x0 = p[k < K ? k : 0], x1 = p[k + 1 < K ? k + 1 : 0], x2 = p[k + 2 < K ? k + 2 : 0],
-                  x3 = p[k + 3 < K ? k + 3 : 0];
-      v[u] = make_float4(ok && k < K ? x0 : 0.f, ok && k + 1 < K ? x1 : 0.f, ok && k + 2 < K ? x2 : 0.f,
-                         ok && k + 3 < K ? x3 : 0.f);
-    }
-  }
+// One layer's weights + bias -> LDS.  The flat parameter group stores every layer as the very image the kernel wants in
+// LDS (porl_qnet_create: round32(N) rows of round16(K) + 4 floats, zero padded, then round32(N) bias floats), so
+// staging is a linear copy: qf_fetch_w requests float4 number u * 256 + t of the image into registers (QF_WREGS per
+// thread cover 128 x 132 + 128), qf_park_w writes them to LDS at the same index.  No per-element address arithmetic,
+// no bounds selects (measured before: ~2.7 k cycles to ISSUE a layer's 17 requests, ~2.5 k to park them).  The kernel
+// fetches stage j+1 before it computes stage j, so the round trip to L2 hides behind the MFMA work.
+constexpr int QF_WREGS = ((QF_MAX_W * (QF_MAX_W + 4) + QF_MAX_W) / 4 + 255) / 256;      // 17
+__device__ __forceinline__ int qf_image4(int N, int K) { return (qf_r32(N) * (qf_rk(K) + 4) + qf_r32(N)) >> 2; }
+// (Fold expressions over a compile-time index pack: every slot is a straight-line statement with a constant index.)
+template <int... U>
+__device__ __forceinline__ void qf_fetch_impl(float4 (&v)[QF_WREGS], const float4* src, int total4, int t,
+                                              std::integer_sequence<int, U...>) {
+  // every slot issues its load unconditionally; slots past the image re-read float4 0 (one shared cache line) and
+  // are replaced by zeros afterwards.  (Without that select the compiler kept `v` in scratch memory: global_load ->
+  // s_waitcnt vmcnt(0) -> scratch_store per slot in the ISA, 85 scratch instructions, +10 % kernel time.)
+  ((v[U] = (U * 256 + t < total4) ? src[U * 256 + t < total4 ? U * 256 + t : 0] : make_float4(0.f, 0.f, 0.f, 0.f)), ...);
 }
-__device__ __forceinline__ void qf_park_w(float* wl, float* bl, const float4 (&v)[QF_WREGS], float bias_reg, int N, int K,
-                                          int t) {
-  const int total4 = qf_r32(N) * ((qf_rk(K) + 4) >> 2);
-  if (t < QF_MAX_W) bl[t] = bias_reg;
-#pragma unroll
-  for (int u = 0; u < QF_WREGS; ++u) {
-    const int i = u * 256 + t;
-    if (i < total4) reinterpret_cast<float4*>(wl)[i] = v[u];
-  }
+template <int... U>
+__device__ __forceinline__ void qf_park_impl(float4* dst, const float4 (&v)[QF_WREGS], int total4, int t,
+                                             std::integer_sequence<int, U...>) {
+  ((U * 256 + t < total4 ? (void)(dst[U * 256 + t] = v[U]) : (void)0), ...);
+}
+__device__ __forceinline__ void qf_fetch_w(float4 (&v)[QF_WREGS], const float* img, int N, int K, int t) {
+  qf_fetch_impl(v, reinterpret_cast<const float4*>(img), qf_image4(N, K), t, std::make_integer_sequence<int, QF_WREGS>{});
+}
+__device__ __forceinline__ void qf_park_w(float* wl, const float4 (&v)[QF_WREGS], int N, int K, int t) {
+  qf_park_impl(reinterpret_cast<float4*>(wl), v, qf_image4(N, K), t, std::make_integer_sequence<int, QF_WREGS>{});
 }
 
 // out[32][ldo] = act(in[32][ldi] . Wl^T + bias): wave w computes the 32-column slabs w, w+4, ...
@@ -186,7 +172,8 @@ __device__ __forceinline__ void qf_forward(const float* in, int ldi, const float
 // ---- loss and dL/dQ: one lane per row  (cql_trainer.py:94-118; same arithmetic as cql_loss_kernel).  dq may be
 // the Q buffer itself: a lane reads q[j] before it writes dq[j].  Leaves the block's partial sums in red[0..1].
 __device__ __forceinline__ void qf_loss_rows(const QnetFusedArgs& a, const float* Q, const float* Qn, float* dz, const int* amax,
-                                             int row0, int lane, int wave, float* red) {
+                                             int row_act, float row_rew, float row_done, int row0, int lane, int wave,
+                                             float* red) {
   const int A = a.dims[a.n_lin], ldq = qf_r32(A) + 4;
   if (wave == 0) {
     float td = 0.f, pen = 0.f;
@@ -201,12 +188,21 @@ __device__ __forceinline__ void qf_loss_rows(const QnetFusedArgs& a, const float
         float se = 0.f;
         for (int j = 0; j < A; ++j) se += expf(q[j] - mx);
         const float lse = mx + logf(se);
-        const long src = a.idx ? a.idx[b] : (long)b;
-        const int act = (int)a.actions[src];
+        const int act = row_act;
         const float qa = q[act];
-        const float qnext = a.double_dqn ? qn[amax[lane]] : mxn;
-        const float y = a.rew[src] + a.gamma * qnext * (1.f - a.done[src]);
-        const float diff = qa - y;
+        float qnext = a.double_dqn ? qn[amax[lane]] : mxn;
+        if (a.next_mask) {
+          const float* mk = a.next_mask + (long)b * A;
+          int best = 0;
+          float bestv = qn[0] + (mk[0] - 1.f) * 1e10f;
+          for (int j = 1; j < A; ++j) {
+            const float v = qn[j] + (mk[j] - 1.f) * 1e10f;
+            if (v > bestv) { bestv = v; best = j; }               // first maximum, like torch.argmax
+          }
+          qnext = qn[best];
+        }
+        const float y = row_rew + a.gamma * qnext * (1.f - row_done);
+        const float diff = a.td_off ? 0.f : qa - y;
         float wgt = a.is_w ? a.is_w[b] : 1.f;
         if (a.w_uniform) wgt *= a.w_uniform[0];
         td = wgt * (diff * diff);
@@ -261,7 +257,7 @@ __device__ __forceinline__ void qf_wgrad(const QnetFusedArgs& a, int l, const fl
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (n < N && k < K) slab[a.w_off[l] + (long)n * K + k] = acc[r];
+      if (n < N && k < K) slab[a.w_off[l] + (long)n * (qf_rk(K) + 4) + k] = acc[r];
     }
   }
   for (int n = t; n < N; n += 256) {
@@ -308,7 +304,6 @@ __device__ __forceinline__ void qf_dgrad(const float* dz, int lddz, const float*
 __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) {
   extern __shared__ float qf_lds[];
   __shared__ float red[2];
-  __shared__ float bl[QF_MAX_W];                     // bias of the layer whose weights sit in wl
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, kh = lane >> 5;
   const int row0 = blockIdx.x * QF_ROWS;
   const int L = a.n_lin - 1;
@@ -319,43 +314,51 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
   // Weight pipeline: stage j = target layer j (j <= L), online layer j-L-1 (j <= 2L+1), then the online layers
   // L..1 again for the backward pass.  Stage j+1 is requested into registers right after stage j is parked in LDS.
   int n_stamp = 0;
-  auto stamp = [&]() {
+  auto stamp = [&]() __attribute__((always_inline)) {
     if (a.stamps && blockIdx.x == 0 && t == 0) a.stamps[n_stamp++] = __builtin_amdgcn_s_memtime();
   };
   stamp();
   float4 wr[QF_WREGS];
-  float br = 0.f;
   const int n0 = a.double_dqn ? L + 1 : 0;          // stages of the leading online pass over s' (Double DQN)
   const int n_stages = n0 + 3 * L + 2;
-  auto stage = [&](int j, const float*& W, const float*& bias, int& N, int& K) {
+  // (always_inline: a lambda left out of line takes `wr` by address, which moves the staging registers to scratch)
+  auto stage = [&](int j, const float*& W, int& N, int& K) __attribute__((always_inline)) {
     const bool lead = j < n0;
     if (!lead) j -= n0;
     const int l = lead ? j : (j <= L ? j : (j <= 2 * L + 1 ? j - L - 1 : 3 * L + 2 - j));
     const float* P = (!lead && j <= L) ? a.params_tgt : a.params;
-    W = P + a.w_off[l]; bias = P + a.b_off[l];
+    W = P + a.w_off[l];                              // the layer's image: weights, then bias
     N = a.dims[l + 1]; K = a.dims[l];
   };
-  auto fetch = [&](int j) {
+  auto fetch = [&](int j) __attribute__((always_inline)) {
     if (j >= n_stages) return;
-    const float* W; const float* bias; int N, K;
-    stage(j, W, bias, N, K);
-    qf_fetch_w(wr, br, W, bias, N, K, t);
+    const float* W; int N, K;
+    stage(j, W, N, K);
+    qf_fetch_w(wr, W, N, K, t);
     // compiler barrier: without it the loads are sunk below the layer's MFMA loop (nothing there depends on them),
     // i.e. issued right before their first use, and every layer pays the full round trip to L2
     asm volatile("" ::: "memory");
   };
-  auto park = [&](int j) {
-    const float* W; const float* bias; int N, K;
-    stage(j, W, bias, N, K);
-    qf_park_w(wl, bl, wr, br, N, K, t);
+  auto park = [&](int j) __attribute__((always_inline)) {
+    const float* W; int N, K;
+    stage(j, W, N, K);
+    qf_park_w(wl, wr, N, K, t);
   };
   fetch(0);
+  // The loss stage's per-row scalars (action, reward, done flag) are requested NOW, by the lanes that will use them
+  // (thread t < 32 = lane t of wave 0 = row t): they sit behind the same index indirection as the rows, and fetching
+  // them only when the loss needs them exposed a full HBM round trip there.  Branch-free; they stay in registers.
+  const int my_row = row0 + (t < QF_ROWS ? t : 0);
+  const long my_src = my_row < a.B ? (a.idx ? a.idx[my_row] : (long)my_row) : 0L;
+  const int row_act = (int)a.actions[my_src];
+  const float row_rew = a.rew[my_src], row_done = a.done[my_src];
 
   // ---- target network on s'  (cql_trainer.py:99-101) ---------------------------------------------------
   // s' waits in tmp[1] (free until the target net's layer 1 writes there), s in the online net's input buffer
   float* Xn = qf_lds + a.lds_tmp[1];
   qf_load_inputs(Xn, X, ldx, a.next_states, a.n_rs, a.states, a.s_rs, a.idx, row0, a.B, a.dims[0], t);
   __shared__ int amax[QF_ROWS];
+
   // Forward passes share ONE copy of the park / fetch / layer code (the kernel runs each instruction once per block,
   // so its size is its instruction-fetch cost): pass 0 = online net on s' (Double DQN only, argmax kept),
   // pass 1 = target net on s' (activations ping-pong in tmp), pass 2 = online net on s (activations kept).
@@ -368,6 +371,7 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
       ++stage_no;
       const float* in = l == 0 ? (pass == 2 ? X : Xn) : (pass == 1 ? qf_lds + a.lds_tmp[(l - 1) & 1] : qf_lds + a.lds_act[l]);
       float* out = pass == 1 ? qf_lds + a.lds_tmp[l & 1] : qf_lds + a.lds_act[l + 1];
+      const float* bl = wl + qf_r32(a.dims[l + 1]) * (qf_rk(a.dims[l]) + 4);       // bias row of the parked image
       qf_forward(in, qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L, out, qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
       qf_barrier();
     }
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
 
   stamp();
   // ---- loss and dL/dQ: one lane per row  (cql_trainer.py:94-118; same arithmetic as cql_loss_kernel) ----
-  qf_loss_rows(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, row0, lane, wave, red);
+  qf_loss_rows(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, row_act, row_rew, row_done, row0, lane, wave, red);
   qf_barrier();
   if (t == 0) { a.part_td[blockIdx.x] = red[0]; a.part_pen[blockIdx.x] = red[1]; }
   stamp();

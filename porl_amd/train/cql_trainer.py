@@ -49,15 +49,18 @@ class QnetEngine:
         return bool(self._lib.porl_qnet_one_launch(self._h))
 
     def tensor_table(self):
+        """[(offset, shape, row stride)] — weight matrices sit inside zero-padded images (include/porl_hip.h)."""
         out = []
-        off, r, c = C.c_int64(), C.c_int32(), C.c_int32()
+        off, r, c, ld = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
         for i in range(int(self._lib.porl_qnet_tensors(self._h))):
-            N.check(self._lib.porl_qnet_tensor_info(self._h, i, C.byref(off), C.byref(r), C.byref(c)))
-            out.append((off.value, (c.value,) if r.value == 0 else (r.value, c.value)))
+            N.check(self._lib.porl_qnet_tensor_info(self._h, i, C.byref(off), C.byref(r), C.byref(c), C.byref(ld)))
+            out.append((off.value, (c.value,) if r.value == 0 else (r.value, c.value), ld.value))
         return out
 
     def views(self, flat):
-        return [flat[o:o + math.prod(s)].view(s) for o, s in self.tensor_table()]
+        """Parameter-shaped views into a flat group (weights: strided (out, in) windows of their padded images)."""
+        return [flat[o:o + s[0]] if len(s) == 1 else flat[o:o + s[0] * ld].view(s[0], ld)[:, :s[1]]
+                for o, s, ld in self.tensor_table()]
 
     def _ensure_bound(self):
         if self.device.type != "cuda":

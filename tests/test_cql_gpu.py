@@ -155,8 +155,9 @@ def test_one_launch_gradients_on_odd_shapes(S, A, B, hidden):
     rng = np.random.default_rng(S * 1000 + A)
     eng = QnetEngine(S, A, hidden, max(B, 64), DEV)
     assert eng.fused
-    eng.params.copy_(torch.from_numpy(rng.uniform(-0.3, 0.3, eng.n_params).astype(np.float32)))
-    eng.params_tgt.copy_(torch.from_numpy(rng.uniform(-0.3, 0.3, eng.n_params).astype(np.float32)))
+    for flat in (eng.params, eng.params_tgt):           # through the parameter views: the images' padding stays zero
+        for v in eng.views(flat):
+            v.copy_(torch.from_numpy(rng.uniform(-0.3, 0.3, tuple(v.shape)).astype(np.float32)))
     st, ac, rw, ns, dn = make_discrete_transitions(B, S, A, seed=8)
     dev = lambda x: torch.from_numpy(x).to(DEV)
     hp = eng.hyper(0.99, 0.7, 1.0 / B, 1, 5e-4)
@@ -172,7 +173,7 @@ def test_one_launch_gradients_on_odd_shapes(S, A, B, hidden):
             E.tune_set("qnet_fused", 1)
     scale = np.abs(out[1][0]).max()
     assert np.abs(out[0][0] - out[1][0]).max() <= 2e-6 * max(scale, 1.0)
-    np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-6)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-6, atol=5e-8)   # (penalty = lse - ln A - q: O(1) terms cancel)
 
 
 def test_wide_networks_keep_the_multi_launch_path():
