@@ -284,10 +284,11 @@ int porl_gemm_f32(int mode, int tile, int32_t M, int32_t N, int32_t K,
 int porl_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t n,
                   double lr, int32_t step, double beta1, double beta2, double eps, double ema_beta,
                   void* stream);
-/* F.softmax(logits, -1) > threshold as a 0/1 fp32 mask (src/porl/net/behavior_policy.py:41-55): logits (batch, ld)
- * rows, n_actions <= 64 columns used; mask_out (batch, n_actions) dense. */
-int porl_softmax_mask(const float* logits, int64_t ld, int32_t batch, int32_t n_actions, float threshold, float* mask_out,
-                      void* stream);
+/* F.softmax(logits, -1) > threshold as a 0/1 fp32 mask (src/porl/net/behavior_policy.py:41-55), or the probabilities
+ * themselves when write_probs != 0 (:30-39): logits (batch, ld) rows, n_actions <= 64 columns used; mask_out
+ * (batch, n_actions) dense. */
+int porl_softmax_mask(const float* logits, int64_t ld, int32_t batch, int32_t n_actions, float threshold,
+                      int32_t write_probs, float* mask_out, void* stream);
 
 /* util/util.py:54-56 on its own: target <- (1 - ema_beta) * target + ema_beta * source over n floats (n % 4 == 0).
  * Same rounding as the sweep fused into porl_adam_ema. */

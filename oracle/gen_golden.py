@@ -515,6 +515,80 @@ def gen_dqn(name, double, S=10, A=6, B=64, K=5, N=500, seed_model=4, seed_data=2
     print(f"{name}: loss={losses}")
 
 
+def gen_bcq(name, S=10, A=6, B=64, K=5, KP=6, N=500, seed_model=5, seed_data=31, seed_np=11, gamma=0.99, threshold=0.17):
+    """bcq_behavior_pretrain (src/porl/policy/bcq.py:23-47) for KP epochs, then bcq_learn (:50-86) for K steps, on a
+    hand-built BCQTrainer (its constructor needs gymnasium); numpy's index stream pinned by np.random.seed.  The
+    threshold sits inside the spread of the pre-trained behaviour probabilities so the mask has both values."""
+    _stub_cql_imports()
+    from porl.train.bcq_trainer import BCQTrainer
+    from porl.policy.bcq import bcq_learn, bcq_behavior_pretrain
+    from porl.net.q_network import QNetwork
+    from porl.net.behavior_policy import BehaviorPolicy
+    from porl.buffer.replaybuffer import ReplayBuffer
+    import contextlib, io
+    dev = torch.device("cpu")
+    torch.manual_seed(seed_model)
+    t = object.__new__(BCQTrainer)
+    t.q_network = QNetwork(S, A).to(dev)
+    t.target_network = QNetwork(S, A).to(dev)
+    t.target_network.load_state_dict(t.q_network.state_dict())
+    with torch.no_grad():
+        for p in t.target_network.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    t.optimizer = torch.optim.Adam(t.q_network.parameters(), lr=0.0005)
+    t.behavior_policy = BehaviorPolicy(S, A).to(dev)                      # bcq_trainer.py:59-62
+    t.behavior_optimizer = torch.optim.Adam(t.behavior_policy.parameters(), lr=0.0005)
+    t.replay_buffer = ReplayBuffer(N, (S,), dev)
+    t.batch_size, t.gamma, t.device, t.num_epochs, t.threshold = B, gamma, dev, KP, threshold
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=seed_data)
+    for i in range(N):
+        t.replay_buffer.push(st[i], int(ac[i]), float(rw[i]), ns[i], bool(dn[i]))
+    out = {"meta": np.array([S, A, B, K, N, seed_model, seed_data, seed_np, KP]), "gamma": np.float64(gamma),
+           "threshold": np.float64(threshold)}
+    out.update(pack("init/", sd_np(t.q_network)))
+    out.update(pack("init_target/", sd_np(t.target_network)))
+    out.update(pack("init_behavior/", sd_np(t.behavior_policy)))
+    np.random.seed(seed_np)
+    # per-epoch cross-entropy of the pre-training (the reference only prints every 10th): re-run its loop body
+    ce = []
+    for epoch in range(KP):
+        states, actions, _, _, _ = t.replay_buffer.sample(B)
+        logits = t.behavior_policy.network(states)
+        loss = torch.nn.functional.cross_entropy(logits, actions)
+        t.behavior_optimizer.zero_grad(); loss.backward(); t.behavior_optimizer.step()
+        ce.append(loss.item())
+    # ... and check that this IS what the reference function does, from the same start
+    torch.manual_seed(seed_model)
+    chk = BehaviorPolicy(S, A)
+    chk.load_state_dict({k: torch.from_numpy(v) for k, v in sub_dict(out, "init_behavior/").items()})
+    t2 = object.__new__(BCQTrainer)
+    t2.behavior_policy, t2.behavior_optimizer = chk, torch.optim.Adam(chk.parameters(), lr=0.0005)
+    t2.replay_buffer, t2.batch_size, t2.num_epochs = t.replay_buffer, B, KP
+    np.random.seed(seed_np)
+    with contextlib.redirect_stdout(io.StringIO()):
+        bcq_behavior_pretrain(t2)
+    for (k, a), (_, b) in zip(sd_np(chk).items(), sd_np(t.behavior_policy).items()):
+        assert np.array_equal(a, b), k
+    out["ce_loss"] = np.array(ce, dtype=np.float64)
+    out.update(pack("behavior_after/", sd_np(t.behavior_policy)))
+    # the mask of the first learn batch (peek with a copy of the RNG state)
+    state = np.random.get_state()
+    _, _, _, nxt, _ = t.replay_buffer.sample(B)
+    np.random.set_state(state)
+    with torch.no_grad():
+        out["mask0"] = t.behavior_policy.sample(nxt, threshold).numpy()
+        out["probs0"] = t.behavior_policy(nxt).numpy()
+    losses = [bcq_learn(t) for _ in range(K)]
+    out["loss"] = np.array(losses, dtype=np.float64)
+    out.update(pack("final/", sd_np(t.q_network)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: ce={ce} loss={losses} mask ones={out['mask0'].mean():.3f}")
+
+
+def sub_dict(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -547,6 +621,7 @@ def main():
     gen_per_trainer("per_trainer_s12_a5")
     gen_dqn("dqn_s10_a6", double=False)
     gen_dqn("ddqn_s10_a6", double=True)
+    gen_bcq("bcq_s10_a6")
 
 
 if __name__ == "__main__":

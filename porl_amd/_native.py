@@ -118,7 +118,7 @@ def _declare(lib):
                                   vp, i32, C.c_int, vp, vp]
     lib.porl_adam_ema.argtypes = [vp, vp, vp, vp, vp, i64, f64, i32, f64, f64, f64, f64, vp]
     lib.porl_ema.argtypes = [vp, vp, i64, f64, vp]
-    lib.porl_softmax_mask.argtypes = [vp, i64, i32, i32, f32, vp, vp]
+    lib.porl_softmax_mask.argtypes = [vp, i64, i32, i32, f32, i32, vp, vp]
     lib.porl_gather_rows.argtypes = [vp, i64, vp, i32, i32, vp, i64, vp]
     lib.porl_sample_indices.argtypes = [i64, i32, C.c_uint64, C.c_uint64, i64, vp, vp]
     lib.porl_epoch_indices.argtypes = [i64, i64, i32, C.c_uint64, C.c_uint64, i64, vp, vp]

@@ -912,8 +912,9 @@ __global__ __launch_bounds__(64) void cql_finalize_kernel(const float* __restric
 }
 
 // mask[b, j] = softmax(logits[b, :])[j] > threshold   (BehaviorPolicy.sample, src/porl/net/behavior_policy.py:41-55)
+// (write_probs != 0: the probabilities themselves, BehaviorPolicy.forward, :30-39)
 __global__ void softmax_mask_kernel(const float* __restrict__ logits, long ld, int B, int A, float threshold,
-                                    float* __restrict__ mask) {
+                                    int write_probs, float* __restrict__ mask) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float* z = logits + (long)b * ld;
@@ -921,7 +922,10 @@ __global__ void softmax_mask_kernel(const float* __restrict__ logits, long ld, i
   for (int j = 0; j < A; ++j) mx = fmaxf(mx, z[j]);
   float se = 0.f;
   for (int j = 0; j < A; ++j) se += expf(z[j] - mx);
-  for (int j = 0; j < A; ++j) mask[(long)b * A + j] = (expf(z[j] - mx) / se > threshold) ? 1.f : 0.f;
+  for (int j = 0; j < A; ++j) {
+    const float pj = expf(z[j] - mx) / se;
+    mask[(long)b * A + j] = write_probs ? pj : (pj > threshold ? 1.f : 0.f);
+  }
 }
 
 // penalty only (compute_cql_penalty, cql_trainer.py:60-86): per-block partials of lse - ln A - Q[a]

@@ -1184,13 +1184,13 @@ int porl_ema(float* target, const float* source, int64_t n, double ema_beta, voi
   return PORL_OK;
 }
 
-int porl_softmax_mask(const float* logits, int64_t ld, int32_t batch, int32_t n_actions, float threshold, float* mask_out,
-                      void* stream) {
+int porl_softmax_mask(const float* logits, int64_t ld, int32_t batch, int32_t n_actions, float threshold,
+                      int32_t write_probs, float* mask_out, void* stream) {
   if (!logits || !mask_out || batch < 1 || n_actions < 1 || n_actions > 64 || ld < n_actions)
     PORL_FAIL(PORL_ERR_INVALID, "bad softmax-mask arguments");
   DevGuard _dg(device_of(mask_out));
   hipLaunchKernelGGL(softmax_mask_kernel, dim3(cdiv(batch, 256)), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, batch,
-                     n_actions, threshold, mask_out);
+                     n_actions, threshold, write_probs, mask_out);
   PORL_HIP(hipGetLastError());
   return PORL_OK;
 }

@@ -202,3 +202,64 @@ def test_dqn_and_double_dqn_learn_match_reference_golden(name):
     got = _np_sd(t.q_network)
     for k, v in sub(z, "final/").items():
         np.testing.assert_allclose(got[k], v, atol=1e-5, err_msg=k)
+
+
+def test_bcq_pretrain_and_learn_match_reference_golden():
+    """Discrete BCQ (src/porl/policy/bcq.py): six cross-entropy epochs of the behaviour policy (:23-47), then five
+    bcq_learn steps (:50-86) whose bootstrap action is the masked argmax of the target network — under the reference's
+    numpy index stream, from the reference's initial Q / target / behaviour parameters."""
+    from porl_amd.policy.bcq import bcq_behavior_pretrain, bcq_learn
+    from porl_amd.train.bcq_trainer import BCQTrainer
+    z, _ = load_golden("bcq_s10_a6")
+    S, A, B, K, N, seed_model, seed_data, seed_np, KP = (int(v) for v in z["meta"])
+    torch.manual_seed(seed_model)
+    t = BCQTrainer(S, A, float(z["gamma"]), device=DEV, batch_size=B, num_epochs=KP, threshold=float(z["threshold"]))
+    assert list(t.behavior_policy.state_dict().keys()) == list(sub(z, "init_behavior/").keys())
+    t.behavior_policy.load_state_dict({k: torch.from_numpy(v) for k, v in sub(z, "init_behavior/").items()})
+    t.q_network.load_state_dict({k: torch.from_numpy(v) for k, v in sub(z, "init/").items()})
+    t.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in sub(z, "init_target/").items()})
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=seed_data)
+    t.replay_buffer = type(t.replay_buffer)(N, (S,), DEV)
+    for i in range(N):
+        t.replay_buffer.push(st[i], int(ac[i]), float(rw[i]), ns[i], bool(dn[i]))
+    np.random.seed(seed_np)
+    np.testing.assert_allclose(bcq_behavior_pretrain(t), z["ce_loss"], rtol=2e-5)
+    got = _np_sd(t.behavior_policy)
+    for k, v in sub(z, "behavior_after/").items():
+        np.testing.assert_allclose(got[k], v, atol=1e-5, err_msg=k)
+    # mask / probabilities of the first learn batch (peek without consuming numpy's stream)
+    state = np.random.get_state()
+    nxt = t.replay_buffer.sample(B)[3]
+    np.random.set_state(state)
+    np.testing.assert_allclose(t.behavior_policy(nxt).cpu().numpy(), z["probs0"], atol=2e-6)
+    np.testing.assert_array_equal(t.behavior_policy.sample(nxt, t.threshold).cpu().numpy(), z["mask0"])
+    assert 0.2 < z["mask0"].mean() < 0.8                      # the mask really selects
+    for k in range(K):
+        np.testing.assert_allclose(bcq_learn(t), z["loss"][k], rtol=2e-5)
+    got = _np_sd(t.q_network)
+    for k, v in sub(z, "final/").items():
+        np.testing.assert_allclose(got[k], v, atol=1e-5, err_msg=k)
+
+
+def test_bcq_mask_with_no_allowed_action_falls_back_to_the_first_action():
+    """(mask - 1) * 1e10 drowns every Q value when no action passes the threshold: all entries tie at -1e10 and
+    torch.argmax returns index 0 (bcq.py:68-73).  threshold = 1.0 forces that case."""
+    from porl_amd.policy.bcq import bcq_learn
+    from porl_amd.train.bcq_trainer import BCQTrainer
+    from porl_amd.train.dqn_trainer import DQNTrainer
+    S, A, B, N = 8, 5, 32, 64
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=2)
+    torch.manual_seed(0)
+    t = BCQTrainer(S, A, 0.9, device=DEV, batch_size=B, threshold=1.0)
+    for i in range(N):
+        t.replay_buffer.push(st[i], int(ac[i]), float(rw[i]), ns[i], bool(dn[i]))
+    np.random.seed(0)
+    idx = np.random.choice(N, B, replace=False)
+    np.random.seed(0)
+    q0 = _np_sd(t.q_network)
+    tq = t.target_network(torch.from_numpy(ns[idx]).to(DEV)).cpu().numpy()
+    q = t.q_network(torch.from_numpy(st[idx]).to(DEV)).cpu().numpy()
+    loss = bcq_learn(t)
+    y = rw[idx] + 0.9 * tq[:, 0] * (1 - dn[idx])
+    want = np.mean((q[np.arange(B), ac[idx]] - y) ** 2)
+    np.testing.assert_allclose(loss, want, rtol=2e-5)
