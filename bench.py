@@ -171,16 +171,17 @@ def bench_sorl_enc(a):
     dev = torch.device("cuda", 0)
     Bq, F, Hq, Aq = a.batch or 512, 256, 512, 2
     torch.manual_seed(0)
-    backbone = FasterNet(3, F, max_batch=Bq)
-    args = SimpleNamespace(state_size=362, feature_dim=F, hidden_dim=Hq, n_hidden=2, layer_norm=False, action_size=Aq,
+    n_ang, n_dist = a.angle_bins, a.dist_bins             # 360 x 256 = the reference's image; 84 x 84 = BASELINE's wording
+    backbone = FasterNet(3, F, max_batch=Bq, angle_bins=n_ang, dist_bins=n_dist)
+    args = SimpleNamespace(state_size=n_ang + 2, feature_dim=F, hidden_dim=Hq, n_hidden=2, layer_norm=False, action_size=Aq,
                            max_batch=Bq)
     agent = SORL(args, max_steps=1000, tau=0.9, alpha=3.0, device=dev, backbone=backbone)
     agent.async_losses = True
     rng = np.random.default_rng(0)
     nb = 4
-    st = np.empty((nb, 2, Bq, 362), dtype=np.float32)
-    st[..., :360] = rng.uniform(0.15, 3.9, size=(nb, 2, Bq, 360))
-    st[..., 360:] = rng.uniform(-3, 3, size=(nb, 2, Bq, 2))
+    st = np.empty((nb, 2, Bq, n_ang + 2), dtype=np.float32)
+    st[..., :n_ang] = rng.uniform(0.15, 3.9, size=(nb, 2, Bq, n_ang))
+    st[..., n_ang:] = rng.uniform(-3, 3, size=(nb, 2, Bq, 2))
     st = torch.from_numpy(st).to(dev)
     act = torch.from_numpy(rng.uniform(-1, 1, size=(nb, Bq, Aq)).astype(np.float32)).to(dev)
     rew = torch.from_numpy(rng.normal(size=(nb, Bq)).astype(np.float32)).to(dev)
@@ -210,12 +211,12 @@ def bench_sorl_enc(a):
     gemms = [p for p in prof if p["name"].startswith("gemm_f32_kernel") and p["launches"]]
     dom = max(gemms, key=lambda p: p["total_ms"])
     ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-    enc_flops = 2 * 2 * Bq * 0.86e9
+    enc_flops = 2 * 2 * Bq * 0.86e9 * (n_ang * n_dist) / (360.0 * 256.0)
     out = {"metric": "gradient-steps/sec (SORL update + FasterNet encoder, batch=512)", "value": a.steps / el,
            "unit": "gradient-steps/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"SORL S=362 F={F} H={Hq} B={Bq} + FasterNet(3,{F}) encoder on 360x256 costmaps, "
+           "config": {"workload": f"SORL S={n_ang + 2} F={F} H={Hq} B={Bq} + FasterNet(3,{F}) encoder on {n_ang}x{n_dist} costmaps, "
                                   "2 encoder forwards (train-mode BN, DropPath) + value/policy update per step"},
            "algorithmic_tflops": enc_flops * a.steps / el / 1e12,
            "roofline": dict(bound="mfma", kernel=dom["name"], achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
@@ -229,8 +230,8 @@ def bench_sorl_enc(a):
         bs = 8
         x = st[0, 0, :bs].cpu().numpy()
         c0 = time.perf_counter()
-        FO.forward(sd, stats, x.copy(), True, np.ones((3, bs), np.float32), dtype=np.float32)
-        FO.forward(sd, stats, x.copy(), True, np.ones((3, bs), np.float32), dtype=np.float32)
+        FO.forward(sd, stats, x.copy(), True, np.ones((3, bs), np.float32), dtype=np.float32, angle_bins=n_ang, dist_bins=n_dist)
+        FO.forward(sd, stats, x.copy(), True, np.ones((3, bs), np.float32), dtype=np.float32, angle_bins=n_ang, dist_bins=n_dist)
         dt = time.perf_counter() - c0
         out["cpu_baseline"] = {"value": (bs / Bq) / dt, "unit": "gradient-steps/sec", "kind": "port", "cores": os.cpu_count(),
                                "sample": f"2 encoder forwards of oracle/fasternet_oracle.py (numpy fp32) on {bs} of the "
@@ -280,6 +281,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows-per-gpu", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--angle-bins", type=int, default=360, help="sorl_enc: costmap rows (360 = the reference's image)")
+    ap.add_argument("--dist-bins", type=int, default=256, help="sorl_enc: costmap columns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",

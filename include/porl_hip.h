@@ -355,6 +355,10 @@ int porl_enc_tensor_info(const porl_enc* h, int32_t index, int64_t* offset, int6
 int porl_enc_norm_info(const porl_enc* h, int32_t index, int64_t* mean_offset, int64_t* var_offset,
                        int32_t* channels, char* name, int32_t name_len);
 int porl_enc_bind(porl_enc* h, float* params, float* bn_stats, float* workspace);
+/* The encoder keeps permuted copies of its convolution weights in the workspace and refreshes them on the first
+ * forward after porl_enc_bind.  Call this after writing new values into `params` (load_state_dict, an optimizer step on
+ * the backbone) so the next forward refreshes them again. */
+int porl_enc_weights_changed(porl_enc* h);
 /* state (batch, n_ang + 2) row stride state_rs, entries > 8 zeroed in place like the reference
  * (util/costmap.py:17); drop_scale (blocks, batch) = DropPath keep mask / keep_prob per MLPBlock and
  * sample (fasternet.py:76-93) or NULL for none; features (batch, num_classes), row stride feat_rs. */

@@ -29,7 +29,7 @@ SYMBOLS = [
     "porl_qnet_forward", "porl_qnet_penalty", "porl_qnet_learn_indexed", "porl_qnet_one_launch", "porl_qnet_learn_variant",
     "porl_enc_create", "porl_enc_destroy", "porl_enc_param_floats", "porl_enc_stat_floats",
     "porl_enc_workspace_floats", "porl_enc_tensors", "porl_enc_norms", "porl_enc_blocks",
-    "porl_enc_tensor_info", "porl_enc_norm_info", "porl_enc_bind", "porl_enc_forward",
+    "porl_enc_tensor_info", "porl_enc_norm_info", "porl_enc_bind", "porl_enc_weights_changed", "porl_enc_forward",
 ]
 
 
@@ -161,6 +161,7 @@ def _declare(lib):
     lib.porl_enc_tensor_info.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64), C.c_char_p, i32]
     lib.porl_enc_norm_info.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.c_char_p, i32]
     lib.porl_enc_bind.argtypes = [vp, vp, vp, vp]
+    lib.porl_enc_weights_changed.argtypes = [vp]
     lib.porl_enc_forward.argtypes = [vp, vp, i64, i32, i32, vp, vp, i64, vp]
     lib.porl_prof_enable.argtypes = [C.c_int]
     lib.porl_prof_read.argtypes = [C.POINTER(ProfEntry), C.c_int]

@@ -89,8 +89,16 @@ class FasterNet(nn.Module):
     def __init__(self, in_chans=3, num_classes=1000, embed_dim=96, depths=(1, 2), mlp_ratio=2., n_div=4,
                  patch_size=4, patch_stride=4, patch_size2=2, patch_stride2=2, patch_norm=True, feature_dim=1280,
                  drop_path_rate=0.1, layer_scale_init_value=0, norm_layer='BN', act_layer='RELU', fork_feat=False,
-                 init_cfg=None, pretrained=None, pconv_fw_type='split_cat', max_batch=512, **kwargs):
+                 init_cfg=None, pretrained=None, pconv_fw_type='split_cat', max_batch=512, angle_bins=None,
+                 dist_bins=None, **kwargs):
         super().__init__()
+        # costmap geometry: the reference rasterises to 360 x 256 (util/costmap.py:7,12,24) and cannot do otherwise;
+        # `angle_bins` / `dist_bins` (multiples of 4) parametrise it, e.g. the 84 x 84 image BASELINE config 5 names.
+        # The state then carries angle_bins beams + the 2 goal coordinates.
+        if angle_bins is not None:
+            self.ANGLE_BINS = int(angle_bins)
+        if dist_bins is not None:
+            self.DIST_BINS = int(dist_bins)
         if norm_layer != 'BN' or act_layer != 'RELU':
             raise NotImplementedError("only norm_layer='BN', act_layer='RELU' (the configuration sorl_train.py builds)")
         if fork_feat or layer_scale_init_value > 0 or not patch_norm or pretrained is not None or init_cfg is not None:
@@ -141,6 +149,12 @@ class FasterNet(nn.Module):
         self._workspace = None
         self._bound = False
         self._adopt(copy_from_modules=True)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.weights_changed())
+
+    def weights_changed(self):
+        """The engine keeps permuted copies of the convolution weights; tell it the parameters were rewritten
+        (called by load_state_dict and .to(); call it yourself after editing parameters in place)."""
+        N.check(self._lib.porl_enc_weights_changed(self._h), "porl_enc_weights_changed")
 
     # reference fasternet.py:380-390
     @staticmethod

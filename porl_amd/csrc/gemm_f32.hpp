@@ -37,9 +37,10 @@ enum : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 // A-operand prologue (applied to the value loaded from memory, before it is staged in LDS)
 enum : int {
   APRO_NONE = 0,
-  // a(b, j) = rowscale[b] * colscale[j] * 1[A(b, j) > 0]   — dZ of the scalar V head made on the fly:
-  // rowscale = dL/dv (B,), colscale = w_out (H,), A = post-ReLU activations of the last hidden layer.
-  APRO_RANK1_MASK = 1,
+  // a(m, k) = max(A(m, k) * colscale[k] + colshift[k], 0): BatchNorm (folded to scale/shift) + ReLU of the producer
+  // applied while the operand is staged, so the normalised activation is never written (the costmap encoder's
+  // W1 -> BN -> ReLU -> W2 chain, agent/fasternet.py:163-166).  k-contiguous A only, K a multiple of the K-tile.
+  APRO_AFFINE_RELU = 1,
 };
 
 struct GemmProb {
@@ -51,9 +52,8 @@ struct GemmProb {
   const float* headw;     // (N,) fused scalar head: headout[part][m] = sum_n C(m,n)*headw[n]
   float* headout;         // (parts, M) with parts = tiles_n * (waves along N), see head_parts()
   float* colsum;          // !A_KC only: (M,) column sums of A over K (bias gradient); slab s at +s*M
-  float* rawdot;          // !A_KC + APRO only: (M,) sum_k rowscale[k] * A_raw(k, m)  (scalar-head weight gradient)
-  const float* a_rowscale;  // APRO_RANK1_MASK
-  const float* a_colscale;  // APRO_RANK1_MASK
+  const float* a_colscale;  // APRO_AFFINE_RELU: (K,) scale
+  const float* a_colshift;  // APRO_AFFINE_RELU: (K,) shift
   const float* resid;     // (M,N) ld=ldc: C = resid + rscale[(row + rs_row0) / rs_rows] * acc (may alias C), or null
   const float* rscale;    // per-sample factor of the residual form (null = 1)
   float* cstat;           // ((M+31)/32, 2, N): per 32-row block, column sums and sums of squares of the stored C
@@ -139,7 +139,7 @@ __device__ unsigned long long g_stamps[16 * 4096];   // per block: entry, loop b
 // writes, waits) runs under the other wave's MFMAs — with 4 waves the matrix pipe idles during it.
 //   VEC : every operand of every problem may be read with 16-byte loads (pointer, leading dimension
 //         and contiguous extent are multiples of 4 floats).  VEC=false reads dwords.
-//   APRO: A-operand prologue enabled (APRO_RANK1_MASK) for every problem of the group.
+//   APRO: A-operand prologue enabled (APRO_AFFINE_RELU) for every problem of the group (forward problems only).
 // Blocks whose tile lies completely inside the problem (and whose K range is a whole number of
 // K-tiles) take an unguarded main loop; edge blocks take the guarded one.
 template <int BM, int BN, int BK, int WM, int WN, bool VEC, bool APRO>
@@ -165,7 +165,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
   static_assert(BM * BK / 4 % THREADS == 0 && BN * BK / 4 % THREADS == 0, "staging must divide evenly");
   static_assert(BK % 4 == 0 && WTM >= 1 && WTN >= 1 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile shape");
 
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
+  // APRO: the (K,) column scale and shift of the operand prologue sit behind the staging buffers (read back with
+  // one ds_read_b128 each when a slot is parked: no extra global loads, no extra registers in the MFMA loop)
+  constexpr int APRO_MAX_K = 1024;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE) + (APRO ? 2 * APRO_MAX_K : 0)];
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -258,17 +261,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
     }
   }
 
-  // rank-1 prologue: element (k, c) of A becomes rowscale[b] * colscale[j] * 1[A > 0] where
-  // (b, j) = (c, k) for k-contiguous A (dgrad) and (k, c) for m-contiguous A (wgrad); the 4 elements
-  // of a slot always run along j (the contiguous, hidden dimension).
-  const float* __restrict__ rsc = APRO ? P.a_rowscale : nullptr;
-  const float* __restrict__ csc = APRO ? P.a_colscale : nullptr;
+  // affine + ReLU prologue: the 4 elements of a slot of a k-contiguous A run along k, so a slot needs the scale and
+  // shift of 4 consecutive columns (one 16-byte load each, issued with the operand request)
+  float* const apro_cs = lds + 2 * (A_TILE + B_TILE);      // [K] scale, then [K] shift at + APRO_MAX_K
+  if constexpr (APRO) {
+    for (int k = t; k < P.K; k += THREADS) { apro_cs[k] = P.a_colscale[k]; apro_cs[APRO_MAX_K + k] = P.a_colshift[k]; }
+    // (made visible by the workgroup barrier that precedes the first use: store_tile of tile 0 runs before it, so
+    // the prologue barrier below is placed ahead of that first store)
+  }
 
   float4 ra[NLA], rb[NLB];
-  float pr_rs[APRO ? NLA : 1];       // prologue row scale (one per slot)
-  float4 pr_cs[APRO ? NLA : 1];      // prologue column scales
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 rdot = make_float4(0.f, 0.f, 0.f, 0.f);
 
   f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -323,20 +326,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
         } else {
           ra[i] = buf_ld128(a_rsrc, sa[i].off, a_soff(kt));
         }
-        if constexpr (APRO) {
-          const int k = sa[i].kpos + kadv, c = sa[i].cpos;
-          const int b0 = a_kc ? c : k, j0 = a_kc ? k : c;
-          if constexpr (GUARD) {
-            pr_rs[i] = *(ok[0] ? rsc + b0 : rsc);
-            pr_cs[i].x = *(ok[0] ? csc + j0 : csc);
-            pr_cs[i].y = *(ok[1] ? csc + j0 + 1 : csc);
-            pr_cs[i].z = *(ok[2] ? csc + j0 + 2 : csc);
-            pr_cs[i].w = *(ok[3] ? csc + j0 + 3 : csc);
-          } else {
-            pr_rs[i] = rsc[b0];
-            pr_cs[i] = *reinterpret_cast<const float4*>(csc + j0);
-          }
-        }
+
       }
 #pragma unroll
       for (int i = 0; i < NLB; ++i) {
@@ -358,15 +348,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
 #pragma unroll
       for (int i = 0; i < NLA; ++i) {
         float4 v = ra[i];
-        if constexpr (APRO) {
-          const float rs = pr_rs[i];
-          if constexpr (!AKC) {      // wgrad blocks also accumulate dv^T H for the output-layer weight
-            rdot.x += rs * v.x; rdot.y += rs * v.y; rdot.z += rs * v.z; rdot.w += rs * v.w;
-          }
-          v.x = v.x > 0.f ? rs * pr_cs[i].x : 0.f;
-          v.y = v.y > 0.f ? rs * pr_cs[i].y : 0.f;
-          v.z = v.z > 0.f ? rs * pr_cs[i].z : 0.f;
-          v.w = v.w > 0.f ? rs * pr_cs[i].w : 0.f;
+        if constexpr (APRO) {      // fmaf then max: the arithmetic of bn_apply_kernel (encoder.hpp)
+          // K is a whole number of K-tiles for APRO problems (host check), so k .. k+3 are always valid columns
+          const int k = sa[i].kpos + kadv;
+          const float4 cs = *reinterpret_cast<const float4*>(apro_cs + k);
+          const float4 cb = *reinterpret_cast<const float4*>(apro_cs + APRO_MAX_K + k);
+          v.x = fmaxf(fmaf(v.x, cs.x, cb.x), 0.f);
+          v.y = fmaxf(fmaf(v.y, cs.y, cb.y), 0.f);
+          v.z = fmaxf(fmaf(v.z, cs.z, cb.z), 0.f);
+          v.w = fmaxf(fmaf(v.w, cs.w, cb.w), 0.f);
         }
         ra[i] = v;
       }
@@ -391,20 +381,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
         } else {
           ra[i] = buf_ld128(a_rsrc, sa[i].off, a_soff(kt));
         }
-        if constexpr (APRO) {
-          const int k = sa[i].kpos + kadv, c = sa[i].cpos;
-          const int b0 = a_kc ? c : k, j0 = a_kc ? k : c;
-          if constexpr (GUARD) {
-            pr_rs[i] = *(ok[0] ? rsc + b0 : rsc);
-            pr_cs[i].x = *(ok[0] ? csc + j0 : csc);
-            pr_cs[i].y = *(ok[1] ? csc + j0 + 1 : csc);
-            pr_cs[i].z = *(ok[2] ? csc + j0 + 2 : csc);
-            pr_cs[i].w = *(ok[3] ? csc + j0 + 3 : csc);
-          } else {
-            pr_rs[i] = rsc[b0];
-            pr_cs[i] = *reinterpret_cast<const float4*>(csc + j0);
-          }
-        }
+
       } else {
         const int i = q - NLA;
         if constexpr (GUARD) {
@@ -423,15 +400,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
       if (q < NLA) {
         const int i = q;
         float4 v = ra[i];
-        if constexpr (APRO) {
-          const float rs = pr_rs[i];
-          if constexpr (!AKC) {
-            rdot.x += rs * v.x; rdot.y += rs * v.y; rdot.z += rs * v.z; rdot.w += rs * v.w;
-          }
-          v.x = v.x > 0.f ? rs * pr_cs[i].x : 0.f;
-          v.y = v.y > 0.f ? rs * pr_cs[i].y : 0.f;
-          v.z = v.z > 0.f ? rs * pr_cs[i].z : 0.f;
-          v.w = v.w > 0.f ? rs * pr_cs[i].w : 0.f;
+        if constexpr (APRO) {      // fmaf then max: the arithmetic of bn_apply_kernel (encoder.hpp)
+          // K is a whole number of K-tiles for APRO problems (host check), so k .. k+3 are always valid columns
+          const int k = sa[i].kpos + kadv;
+          const float4 cs = *reinterpret_cast<const float4*>(apro_cs + k);
+          const float4 cb = *reinterpret_cast<const float4*>(apro_cs + APRO_MAX_K + k);
+          v.x = fmaxf(fmaf(v.x, cs.x, cb.x), 0.f);
+          v.y = fmaxf(fmaf(v.y, cs.y, cb.y), 0.f);
+          v.z = fmaxf(fmaf(v.z, cs.z, cb.z), 0.f);
+          v.w = fmaxf(fmaf(v.w, cs.w, cb.w), 0.f);
         }
         *reinterpret_cast<float4*>(As + sa[i].lds) = v;
         if constexpr (CSUM) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
@@ -530,6 +507,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
 
     if (nkt > 0) {
       load_tile(ktile(0));
+      if constexpr (APRO) __syncthreads();       // the scale / shift table in LDS is complete
       store_tile(ktile(0), 0);
     }
     if (nkt > 1) load_tile(ktile(1));
@@ -595,7 +573,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
   // one specialised copy of the loop per operand-layout pair (uniform per block)
   auto run = [&](auto guard_tag) {
     if (a_kc && b_kc) {
-      if constexpr (!APRO) main_loop(guard_tag, BoolTag<true>{}, BoolTag<true>{}, BoolTag<false>{});   // forward
+      main_loop(guard_tag, BoolTag<true>{}, BoolTag<true>{}, BoolTag<false>{});   // forward
+    } else if constexpr (APRO) {
+      // the prologue instantiation only serves forward problems (host check in launch_tile)
     } else if (a_kc) {
       main_loop(guard_tag, BoolTag<true>{}, BoolTag<false>{}, BoolTag<false>{});
     } else if (do_colsum) {   // only the tn == 0 column of blocks pays for the bias-gradient sums
@@ -637,9 +617,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
       __syncthreads();
     };
     reduce_cols(csum, P.colsum + (size_t)split * M);
-    if constexpr (APRO) {
-      if (P.rawdot) reduce_cols(rdot, P.rawdot + (size_t)split * M);
-    }
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------
@@ -871,10 +848,23 @@ inline hipError_t launch_tile(const GemmGroup& g, hipStream_t s) {
     vec = vec && g.p[i].a_vec && g.p[i].b_vec;
     if ((g.p[i].apro != APRO_NONE) != apro) return hipErrorInvalidValue;   // a group shares the prologue
   }
-  // The rank-1 A-operand prologue (APRO) is kept in the kernel source for reference but is no longer
-  // instantiated: VALU issued between f32 MFMAs is not free on gfx950, so the engine materialises dZ of the
-  // top layer with relu_head_bwd_kernel instead.
-  if (apro) return hipErrorInvalidValue;
+  if (apro) {
+    // affine + ReLU prologue: instantiated for the two tiles the encoder's W2 products use, 16-byte operands,
+    // forward layout, K a whole number of K-tiles (the column scale / shift are read unguarded)
+    if constexpr ((BM == 64 && BN == 64) || (BM == 128 && BN == 64)) {
+      for (int i = 0; i < g.nprob; ++i) {
+        const GemmProb& p = g.p[i];
+        if (!p.a_kc || !p.b_kc || p.K % GEMM_BK || p.splitk > 1 || !p.a_colscale || !p.a_colshift || !vec ||
+            (reinterpret_cast<uintptr_t>(p.a_colscale) & 15u) || (reinterpret_cast<uintptr_t>(p.a_colshift) & 15u))
+          return hipErrorInvalidValue;
+        if (p.K > 1024) return hipErrorInvalidValue;          // APRO_MAX_K: the scale / shift table lives in LDS
+      }
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, true, true>), grid, block, pad, s, g);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, true, false>), grid, block, pad, s, g);
   else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, false, false>), grid, block, pad, s, g);
   return hipGetLastError();
