@@ -223,6 +223,28 @@ int porl_qnet_load_batch(porl_qnet* h, int32_t batch, const float* states, int64
 /* cql_trainer.py:94-111: both forwards, TD + penalty, backward -> grads, stats[0..2]. */
 int porl_qnet_cql_backward(porl_qnet* h, const porl_qnet_hyper* hp, void* stream);
 /* cql_trainer.py:112-113: Adam step. */
+/* Building blocks for losses computed outside the engine (QR-DQN, C51 — porl_qr_loss / porl_c51_loss below): forward of
+ * the online (which_params 0) / target (1) network on the loaded batch's states (which_input 0) / next states (1) into
+ * out (batch, n_actions) [here n_actions = all outputs, e.g. actions x quantiles]; keep != 0 retains the activations
+ * for porl_qnet_backward, which back-propagates a caller-supplied dL/d(output) and leaves the complete gradient in
+ * `grads` (porl_qnet_apply then runs Adam). */
+int porl_qnet_forward_loaded(porl_qnet* h, int which_params, int which_input, int keep, float* out, int64_t out_rs,
+                             void* stream);
+int porl_qnet_backward(porl_qnet* h, const float* dout, int64_t dout_rs, void* stream);
+
+/* QR-DQN quantile-Huber loss (src/porl/train/qr_dqn_trainer.py:97-205): rows of (n_actions, n_quantiles) quantile values
+ * with row stride ld; dz_out = dL/d(z_cur) for loss = mean_b row_loss[b] (1/batch already applied), row_loss (batch,). */
+int porl_qr_loss(const float* z_cur, const float* z_next_online, const float* z_next_target, int64_t ld,
+                 const int64_t* actions, const float* rewards, const float* dones, int32_t batch, int32_t n_actions,
+                 int32_t n_quantiles, float gamma, float kappa, float* dz_out, float* row_loss, void* stream);
+/* C51 projection + cross-entropy (src/porl/train/c51_trainer.py:52-174) on PRE-softmax outputs (the log_softmax of
+ * categorical_q_network.py:76-78 is applied inside, to both networks' rows). */
+int porl_c51_loss(const float* logits_cur, const float* logits_next_target, int64_t ld, const int64_t* actions,
+                  const float* rewards, const float* dones, const float* support, int32_t batch, int32_t n_actions,
+                  int32_t n_atoms, float gamma, float v_min, float v_max, float* dlogits_out, float* row_loss, void* stream);
+/* out[0] = mean(x[0..n)) with a fixed summation order (loss reporting). */
+int porl_reduce_mean(const float* x, int32_t n, float* out, void* stream);
+
 int porl_qnet_apply(porl_qnet* h, const porl_qnet_hyper* hp, void* stream);
 int porl_qnet_learn(porl_qnet* h, const porl_qnet_hyper* hp, void* stream);   /* the two above */
 /* target_network.load_state_dict(q_network.state_dict()) */
@@ -285,7 +307,8 @@ int porl_adam_ema(float* p, const float* g, float* m, float* v, float* target, i
                   double lr, int32_t step, double beta1, double beta2, double eps, double ema_beta,
                   void* stream);
 /* F.softmax(logits, -1) > threshold as a 0/1 fp32 mask (src/porl/net/behavior_policy.py:41-55), or the probabilities
- * themselves when write_probs != 0 (:30-39): logits (batch, ld) rows, n_actions <= 64 columns used; mask_out
+ * themselves when write_probs == 1 (:30-39), or log_softmax when write_probs == 2: logits (batch, ld) rows, n_actions
+ * columns used; mask_out
  * (batch, n_actions) dense. */
 int porl_softmax_mask(const float* logits, int64_t ld, int32_t batch, int32_t n_actions, float threshold,
                       int32_t write_probs, float* mask_out, void* stream);

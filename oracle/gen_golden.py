@@ -585,6 +585,90 @@ def gen_bcq(name, S=10, A=6, B=64, K=5, KP=6, N=500, seed_model=5, seed_data=31,
     print(f"{name}: ce={ce} loss={losses} mask ones={out['mask0'].mean():.3f}")
 
 
+def _fill_replay(t, N, S, A, seed_data, reward_scale=1.0):
+    from porl.buffer.replaybuffer import ReplayBuffer
+    t.replay_buffer = ReplayBuffer(N, (S,), torch.device("cpu"))
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=seed_data)
+    for i in range(N):
+        t.replay_buffer.push(st[i], int(ac[i]), float(rw[i]) * reward_scale, ns[i], bool(dn[i]))
+
+
+def gen_qr(name, S=9, A=5, NQ=12, hidden=(48, 40), B=48, K=5, N=400, seed_model=6, seed_data=37, seed_np=13, gamma=0.97,
+           kappa=0.6):
+    """QRDQNTrainer.learn (src/porl/train/qr_dqn_trainer.py:97-215) on a hand-built trainer (the constructor needs
+    gymnasium); kappa below 1 so both Huber branches occur; the target net differs from the online net."""
+    _stub_cql_imports()
+    from porl.train.qr_dqn_trainer import QRDQNTrainer
+    from porl.net.qr_dqn_network import QRNetwork
+    dev = torch.device("cpu")
+    torch.manual_seed(seed_model)
+    t = object.__new__(QRDQNTrainer)
+    t.q_network = QRNetwork(S, A, NQ, list(hidden))
+    t.target_network = QRNetwork(S, A, NQ, list(hidden))
+    t.target_network.load_state_dict(t.q_network.state_dict())
+    with torch.no_grad():
+        for p in t.target_network.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    t.optimizer = torch.optim.Adam(t.q_network.parameters(), lr=5e-4)
+    t.batch_size, t.gamma, t.device, t.num_quantiles, t.kappa = B, gamma, dev, NQ, kappa
+    i = torch.arange(0, NQ, dtype=torch.float32)
+    t.tau = ((2 * i + 1) / (2 * NQ)).unsqueeze(0)
+    _fill_replay(t, N, S, A, seed_data)
+    out = {"meta": np.array([S, A, NQ, B, K, N, seed_model, seed_data, seed_np] + list(hidden)), "gamma": np.float64(gamma),
+           "kappa": np.float64(kappa)}
+    out.update(pack("init/", sd_np(t.q_network)))
+    out.update(pack("init_target/", sd_np(t.target_network)))
+    np.random.seed(seed_np)
+    losses = [QRDQNTrainer.learn(t) for _ in range(K)]
+    out["loss"] = np.array(losses, dtype=np.float64)
+    out.update(pack("final/", sd_np(t.q_network)))
+    x = torch.from_numpy(make_discrete_transitions(4, S, A, seed=1)[0])
+    with torch.no_grad():
+        out["probe_x"] = x.numpy()
+        out["probe_mean_q"] = t.q_network.get_mean_q_values(x).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={losses}")
+
+
+def gen_c51(name, S=9, A=5, NA=21, hidden=(48, 40), B=48, K=5, N=400, seed_model=7, seed_data=41, seed_np=17, gamma=0.97,
+            v_min=-4.0, v_max=4.0):
+    """C51Trainer.learn (src/porl/train/c51_trainer.py:52-174) on a hand-built trainer; rewards scaled by 2 so that
+    projected atoms hit both clamps of the support."""
+    _stub_cql_imports()
+    from porl.train.c51_trainer import C51Trainer
+    from porl.net.categorical_q_network import CategoricalQNetwork
+    dev = torch.device("cpu")
+    torch.manual_seed(seed_model)
+    t = object.__new__(C51Trainer)
+    t.q_network = CategoricalQNetwork(S, A, NA, v_min, v_max, hidden_sizes=list(hidden))
+    t.target_network = CategoricalQNetwork(S, A, NA, v_min, v_max, hidden_sizes=list(hidden))
+    t.target_network.load_state_dict(t.q_network.state_dict())
+    with torch.no_grad():
+        for p in t.target_network.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    t.optimizer = torch.optim.Adam(t.q_network.parameters(), lr=5e-4)
+    t.batch_size, t.gamma, t.device = B, gamma, dev
+    t.atom_size, t.v_min, t.v_max = NA, v_min, v_max
+    t.delta_z = (v_max - v_min) / (NA - 1)
+    t.support = torch.linspace(v_min, v_max, NA)
+    _fill_replay(t, N, S, A, seed_data, reward_scale=2.0)
+    out = {"meta": np.array([S, A, NA, B, K, N, seed_model, seed_data, seed_np] + list(hidden)), "gamma": np.float64(gamma),
+           "v_min": np.float64(v_min), "v_max": np.float64(v_max)}
+    out.update(pack("init/", sd_np(t.q_network)))
+    out.update(pack("init_target/", sd_np(t.target_network)))
+    np.random.seed(seed_np)
+    losses = [C51Trainer.learn(t) for _ in range(K)]
+    out["loss"] = np.array(losses, dtype=np.float64)
+    out.update(pack("final/", sd_np(t.q_network)))
+    x = torch.from_numpy(make_discrete_transitions(4, S, A, seed=1)[0])
+    with torch.no_grad():
+        out["probe_x"] = x.numpy()
+        out["probe_logp"] = t.q_network(x).numpy()
+        out["probe_q"] = t.q_network.get_q_values(x).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={losses}")
+
+
 def sub_dict(d, prefix):
     return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
 
@@ -622,6 +706,8 @@ def main():
     gen_dqn("dqn_s10_a6", double=False)
     gen_dqn("ddqn_s10_a6", double=True)
     gen_bcq("bcq_s10_a6")
+    gen_qr("qrdqn_s9_a5_n12")
+    gen_c51("c51_s9_a5_n21")
 
 
 if __name__ == "__main__":

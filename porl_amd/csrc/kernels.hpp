@@ -912,7 +912,8 @@ __global__ __launch_bounds__(64) void cql_finalize_kernel(const float* __restric
 }
 
 // mask[b, j] = softmax(logits[b, :])[j] > threshold   (BehaviorPolicy.sample, src/porl/net/behavior_policy.py:41-55)
-// (write_probs != 0: the probabilities themselves, BehaviorPolicy.forward, :30-39)
+// (write_probs == 1: the probabilities themselves, BehaviorPolicy.forward, :30-39; == 2: log-probabilities, the
+// log_softmax over the atoms that ends CategoricalQNetwork.forward, categorical_q_network.py:76-78)
 __global__ void softmax_mask_kernel(const float* __restrict__ logits, long ld, int B, int A, float threshold,
                                     int write_probs, float* __restrict__ mask) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -924,7 +925,7 @@ __global__ void softmax_mask_kernel(const float* __restrict__ logits, long ld, i
   for (int j = 0; j < A; ++j) se += expf(z[j] - mx);
   for (int j = 0; j < A; ++j) {
     const float pj = expf(z[j] - mx) / se;
-    mask[(long)b * A + j] = write_probs ? pj : (pj > threshold ? 1.f : 0.f);
+    mask[(long)b * A + j] = write_probs == 2 ? z[j] - mx - logf(se) : (write_probs ? pj : (pj > threshold ? 1.f : 0.f));
   }
 }
 

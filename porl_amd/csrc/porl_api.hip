@@ -15,6 +15,7 @@
 #include "kernels.hpp"
 #include "qnet_fused.hpp"
 #include "per_tree.hpp"
+#include "dist_losses.hpp"
 
 using namespace porl;
 
@@ -1185,9 +1186,17 @@ int porl_ema(float* target, const float* source, int64_t n, double ema_beta, voi
   return PORL_OK;
 }
 
+int porl_reduce_mean(const float* x, int32_t n, float* out, void* stream) {
+  if (!x || !out || n < 1) PORL_FAIL(PORL_ERR_INVALID, "bad arguments");
+  DevGuard _dg(device_of(out));
+  ReduceArgs r{};
+  add_reduce(r, out, x, 1, 1, n, 0, 1.0f / n);          // fixed summation order (multi_reduce_kernel)
+  return launch_reduce(r, (hipStream_t)stream);
+}
+
 int porl_softmax_mask(const float* logits, int64_t ld, int32_t batch, int32_t n_actions, float threshold,
                       int32_t write_probs, float* mask_out, void* stream) {
-  if (!logits || !mask_out || batch < 1 || n_actions < 1 || n_actions > 64 || ld < n_actions)
+  if (!logits || !mask_out || batch < 1 || n_actions < 1 || n_actions > 4096 || ld < n_actions)
     PORL_FAIL(PORL_ERR_INVALID, "bad softmax-mask arguments");
   DevGuard _dg(device_of(mask_out));
   hipLaunchKernelGGL(softmax_mask_kernel, dim3(cdiv(batch, 256)), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, batch,
@@ -1362,7 +1371,7 @@ int porl_qnet_create(const porl_qnet_cfg* c, porl_qnet** out) {
   if (!c || !out) PORL_FAIL(PORL_ERR_INVALID, "null argument");
   if (c->state_dim < 1 || c->n_actions < 1 || c->max_batch < 1) PORL_FAIL(PORL_ERR_INVALID, "dimensions must be positive");
   if (c->n_hidden < 1 || c->n_hidden > PORL_MAX_HIDDEN) PORL_FAIL(PORL_ERR_INVALID, "n_hidden must be in [1,%d]", PORL_MAX_HIDDEN);
-  if (c->n_actions > 64) PORL_FAIL(PORL_ERR_UNSUPPORTED, "n_actions > 64");
+  if (c->n_actions > 4096) PORL_FAIL(PORL_ERR_UNSUPPORTED, "more than 4096 outputs");   // (A x N outputs of the distributional nets)
   porl_qnet* h = new porl_qnet();
   h->cfg = *c;
   const int L = c->n_hidden, B = c->max_batch;
@@ -1582,39 +1591,11 @@ static int qnet_fused_backward(porl_qnet* h, const porl_qnet_hyper* hp, int B, c
   return PORL_OK;
 }
 
-int porl_qnet_cql_backward(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
-  PORL_TRY(qnet_ready(h, true)); DevGuard _dg(h->device);
-  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
-  hipStream_t s = (hipStream_t)stream;
-  const int B = h->batch, L = h->cfg.n_hidden, A = h->cfg.n_actions;
+// backward of the multi-launch path from dL/d(output) `dz` (B, ld[L]): dW_l = dZ_l^T In_l (split over the batch),
+// dZ_{l-1} = (dZ_l W_l) . 1[In_l > 0], top down; needs the online forward's activations in ws.act[] and the batch in ws.xs
+static int qnet_backward_chain(porl_qnet* h, float* dz, int B, hipStream_t s) {
+  const int L = h->cfg.n_hidden;
   float* W = h->buf.workspace;
-  if (h->fused_ok && g_qnet_fused)
-    return qnet_fused_backward(h, hp, B, W + h->ws.xs, h->Sp, W + h->ws.xn, h->Sp,
-                               reinterpret_cast<const int64_t*>(W + h->ws.actions), W + h->ws.rew, W + h->ws.done, nullptr, s);
-  // forward: target net on s' (activations ping-pong in tmp), online net on s (activations kept)
-  float* dst[2][PORL_MAX_HIDDEN + 1];
-  for (int l = 0; l <= L; ++l) { dst[0][l] = W + h->ws.tmp[l & 1]; dst[1][l] = W + h->ws.act[l]; }
-  const float* params[2] = {h->buf.params_tgt, h->buf.params};
-  const float* inputs[2] = {W + h->ws.xn, W + h->ws.xs};
-  PORL_TRY(qnet_forward(h, 2, params, inputs, dst, B, s));
-  float* Qn = dst[0][L];
-  float* Q = dst[1][L];
-  float* dz = W + h->ws.dz[L & 1];
-  const int nblk = cdiv(B, 256);
-  {
-    CqlLossArgs a{};
-    a.Q = Q; a.Qn = Qn; a.ldq = h->ld[L];
-    a.actions = reinterpret_cast<const int64_t*>(W + h->ws.actions); a.rew = W + h->ws.rew; a.done = W + h->ws.done;
-    a.dQ = dz; a.part_td = W + h->ws.part_td; a.part_pen = W + h->ws.part_pen;
-    a.B = B; a.A = A; a.gamma = hp->gamma; a.alpha = hp->alpha; a.inv_batch = hp->inv_batch;
-    a.log_A = (float)std::log((double)A);
-    hipLaunchKernelGGL(cql_loss_kernel, dim3(nblk), dim3(256), 0, s, a);
-    PORL_HIP(hipGetLastError());
-    hipLaunchKernelGGL(cql_finalize_kernel, dim3(1), dim3(64), 0, s, W + h->ws.part_td, W + h->ws.part_pen, nblk,
-                       hp->inv_batch, hp->alpha, h->buf.stats);
-    PORL_HIP(hipGetLastError());
-  }
-  // backward, top down: dW_l = dZ_l^T In_l (split over the batch), dZ_{l-1} = (dZ_l W_l) . 1[In_l > 0]
   float* G = h->buf.grads;
   ReduceArgs red{};
   float* slab = W + h->ws.slab;
@@ -1652,6 +1633,123 @@ int porl_qnet_cql_backward(porl_qnet* h, const porl_qnet_hyper* hp, void* stream
     if (red.njobs == 8 || l == 0) { PORL_TRY(launch_reduce(red, s)); red = ReduceArgs{}; }
     dz = dz_next;
   }
+  return PORL_OK;
+}
+
+int porl_qnet_cql_backward(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
+  PORL_TRY(qnet_ready(h, true)); DevGuard _dg(h->device);
+  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+  hipStream_t s = (hipStream_t)stream;
+  const int B = h->batch, L = h->cfg.n_hidden, A = h->cfg.n_actions;
+  float* W = h->buf.workspace;
+  if (h->fused_ok && g_qnet_fused)
+    return qnet_fused_backward(h, hp, B, W + h->ws.xs, h->Sp, W + h->ws.xn, h->Sp,
+                               reinterpret_cast<const int64_t*>(W + h->ws.actions), W + h->ws.rew, W + h->ws.done, nullptr, s);
+  // forward: target net on s' (activations ping-pong in tmp), online net on s (activations kept)
+  float* dst[2][PORL_MAX_HIDDEN + 1];
+  for (int l = 0; l <= L; ++l) { dst[0][l] = W + h->ws.tmp[l & 1]; dst[1][l] = W + h->ws.act[l]; }
+  const float* params[2] = {h->buf.params_tgt, h->buf.params};
+  const float* inputs[2] = {W + h->ws.xn, W + h->ws.xs};
+  PORL_TRY(qnet_forward(h, 2, params, inputs, dst, B, s));
+  float* Qn = dst[0][L];
+  float* Q = dst[1][L];
+  float* dz = W + h->ws.dz[L & 1];
+  const int nblk = cdiv(B, 256);
+  {
+    CqlLossArgs a{};
+    a.Q = Q; a.Qn = Qn; a.ldq = h->ld[L];
+    a.actions = reinterpret_cast<const int64_t*>(W + h->ws.actions); a.rew = W + h->ws.rew; a.done = W + h->ws.done;
+    a.dQ = dz; a.part_td = W + h->ws.part_td; a.part_pen = W + h->ws.part_pen;
+    a.B = B; a.A = A; a.gamma = hp->gamma; a.alpha = hp->alpha; a.inv_batch = hp->inv_batch;
+    a.log_A = (float)std::log((double)A);
+    hipLaunchKernelGGL(cql_loss_kernel, dim3(nblk), dim3(256), 0, s, a);
+    PORL_HIP(hipGetLastError());
+    hipLaunchKernelGGL(cql_finalize_kernel, dim3(1), dim3(64), 0, s, W + h->ws.part_td, W + h->ws.part_pen, nblk,
+                       hp->inv_batch, hp->alpha, h->buf.stats);
+    PORL_HIP(hipGetLastError());
+  }
+  return qnet_backward_chain(h, dz, B, s);
+}
+
+// ---- general forward / backward pieces for losses computed outside the engine (QR-DQN, C51: dist_losses.hpp) ----------
+// Forward of the online (which_params = 0) or target (1) network on the LOADED batch's states (which_input = 0) or
+// next states (1); out (batch, n_outputs) with row stride out_rs.  keep != 0 stores the hidden activations for
+// porl_qnet_backward (online network on the states only).
+int porl_qnet_forward_loaded(porl_qnet* h, int which_params, int which_input, int keep, float* out, int64_t out_rs,
+                             void* stream) {
+  PORL_TRY(qnet_ready(h, true)); DevGuard _dg(h->device);
+  if (!out || out_rs < h->cfg.n_actions) PORL_FAIL(PORL_ERR_INVALID, "bad output");
+  if (keep && (which_params != 0 || which_input != 0)) PORL_FAIL(PORL_ERR_INVALID, "keep: online network on the states only");
+  hipStream_t s = (hipStream_t)stream;
+  const int L = h->cfg.n_hidden, B = h->batch;
+  float* W = h->buf.workspace;
+  float* dst[1][PORL_MAX_HIDDEN + 1];
+  for (int l = 0; l <= L; ++l) dst[0][l] = keep ? W + h->ws.act[l] : W + h->ws.tmp[l & 1];
+  const float* params[1] = {which_params ? h->buf.params_tgt : h->buf.params};
+  const float* inputs[1] = {W + (which_input ? h->ws.xn : h->ws.xs)};
+  PORL_TRY(qnet_forward(h, 1, params, inputs, dst, B, s));
+  PackArgs a{};
+  a.rows = B; a.njobs = 1;
+  a.job[0].src = dst[0][L]; a.job[0].dst = out; a.job[0].src_row_stride = h->ld[L]; a.job[0].src_col_stride = 1;
+  a.job[0].cols = h->cfg.n_actions; a.job[0].ld = (int)out_rs;
+  const long n = (long)B * out_rs;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024), 1), dim3(256), 0, s, a);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+// Backward from dL/d(output) `dout` (batch, n_outputs; row stride dout_rs) through the online network whose forward was
+// kept by porl_qnet_forward_loaded: leaves the gradient in grads (complete: slabs combined); porl_qnet_apply follows.
+int porl_qnet_backward(porl_qnet* h, const float* dout, int64_t dout_rs, void* stream) {
+  PORL_TRY(qnet_ready(h, true)); DevGuard _dg(h->device);
+  if (!dout || dout_rs < h->cfg.n_actions) PORL_FAIL(PORL_ERR_INVALID, "bad gradient input");
+  hipStream_t s = (hipStream_t)stream;
+  const int L = h->cfg.n_hidden, B = h->batch;
+  float* W = h->buf.workspace;
+  float* dz = W + h->ws.dz[L & 1];
+  PackArgs a{};
+  a.rows = B; a.njobs = 1;
+  a.job[0].src = dout; a.job[0].dst = dz; a.job[0].src_row_stride = dout_rs; a.job[0].src_col_stride = 1;
+  a.job[0].cols = h->cfg.n_actions; a.job[0].ld = h->ld[L];
+  const long n = (long)B * h->ld[L];
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024), 1), dim3(256), 0, s, a);
+  PORL_HIP(hipGetLastError());
+  return qnet_backward_chain(h, dz, B, s);
+}
+
+static int dist_args_ok(int B, int A, int N, int64_t ld) {
+  if (B < 1 || A < 1 || N < 1 || N > DIST_MAX_N || ld < (int64_t)A * N) PORL_FAIL(PORL_ERR_INVALID, "bad distributional-loss shapes (N <= %d)", DIST_MAX_N);
+  return 0;
+}
+
+int porl_qr_loss(const float* z_cur, const float* z_next_online, const float* z_next_target, int64_t ld, const int64_t* actions,
+                 const float* rewards, const float* dones, int32_t batch, int32_t n_actions, int32_t n_quantiles, float gamma,
+                 float kappa, float* dz_out, float* row_loss, void* stream) {
+  if (!z_cur || !z_next_online || !z_next_target || !actions || !rewards || !dones || !dz_out || !row_loss)
+    PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  PORL_TRY(dist_args_ok(batch, n_actions, n_quantiles, ld));
+  DevGuard _dg(device_of(dz_out));
+  QrLossArgs a{z_cur, z_next_online, z_next_target, (long)ld, actions, rewards, dones, dz_out, row_loss, batch, n_actions,
+               n_quantiles, gamma, kappa, 1.0f / batch};
+  hipLaunchKernelGGL(qr_loss_kernel, dim3(cdiv(batch, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_c51_loss(const float* logits_cur, const float* logits_next_target, int64_t ld, const int64_t* actions,
+                  const float* rewards, const float* dones, const float* support, int32_t batch, int32_t n_actions,
+                  int32_t n_atoms, float gamma, float v_min, float v_max, float* dlogits_out, float* row_loss, void* stream) {
+  if (!logits_cur || !logits_next_target || !actions || !rewards || !dones || !support || !dlogits_out || !row_loss)
+    PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  PORL_TRY(dist_args_ok(batch, n_actions, n_atoms, ld));
+  if (n_atoms < 2 || !(v_max > v_min)) PORL_FAIL(PORL_ERR_INVALID, "need n_atoms >= 2 and v_max > v_min");
+  DevGuard _dg(device_of(dlogits_out));
+  // delta_z as the reference forms it (python double (v_max - v_min) / (atom_size - 1), meeting fp32 tensors as fp32)
+  const float delta = (float)(((double)v_max - (double)v_min) / (double)(n_atoms - 1));
+  C51LossArgs a{logits_cur, logits_next_target, (long)ld, actions, rewards, dones, support, dlogits_out, row_loss, batch, n_actions,
+                n_atoms, gamma, v_min, v_max, delta, 1.0f / batch};
+  hipLaunchKernelGGL(c51_loss_kernel, dim3(cdiv(batch, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  PORL_HIP(hipGetLastError());
   return PORL_OK;
 }
 
