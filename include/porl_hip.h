@@ -237,6 +237,12 @@ int porl_qnet_backward(porl_qnet* h, const float* dout, int64_t dout_rs, void* s
 int porl_qr_loss(const float* z_cur, const float* z_next_online, const float* z_next_target, int64_t ld,
                  const int64_t* actions, const float* rewards, const float* dones, int32_t batch, int32_t n_actions,
                  int32_t n_quantiles, float gamma, float kappa, float* dz_out, float* row_loss, void* stream);
+/* IQN quantile-Huber loss head only (src/porl/train/iqn_trainer.py:136-149): current (batch, n_current) quantile values
+ * of the taken actions at fractions taus (batch, n_current), target (batch, n_target) Bellman targets; dcurrent_out =
+ * dL/dcurrent for loss = mean_b row_loss[b].  (Upstream's IQNTrainer / IQNNetwork pair cannot run as shipped, so there is
+ * no learn() to mirror.) */
+int porl_iqn_quantile_huber(const float* current, const float* target, const float* taus, int32_t batch, int32_t n_current,
+                            int32_t n_target, float kappa, float* dcurrent_out, float* row_loss, void* stream);
 /* C51 projection + cross-entropy (src/porl/train/c51_trainer.py:52-174) on PRE-softmax outputs (the log_softmax of
  * categorical_q_network.py:76-78 is applied inside, to both networks' rows). */
 int porl_c51_loss(const float* logits_cur, const float* logits_next_target, int64_t ld, const int64_t* actions,

@@ -408,6 +408,39 @@ def gen_sorl_enc(name, B=6, K=3, H=64, L=2, A=2, F=256, seed_model=0, seed_data=
     print(f"{name}: losses={losses}")
 
 
+def gen_por_enc(name, B=4, K=2, H=64, L=2, F=256, seed_model=0, seed_data=53, seed_fwd=78, alpha=10.0, tau=0.9):
+    """POR.por_residual_update with backbone=FasterNet(3, F) (agent/por.py:46-57,75-79): heads on the features, the goal
+    policy regresses the raw 362-wide next state."""
+    from agent.fasternet import FasterNet
+    from agent.por import POR
+    torch.manual_seed(seed_model)
+    backbone = FasterNet(3, F)
+    args = SimpleNamespace(state_size=362, feature_dim=F, hidden_dim=H, n_hidden=L, layer_norm=False, action_size=2)
+    agent = POR(args, max_steps=50, tau=tau, alpha=alpha, backbone=backbone)
+    out = {"seed_model": np.int64(seed_model), "seed_fwd": np.int64(seed_fwd), "meta": np.array([B, K, H, L, F]),
+           "alpha": np.float64(alpha), "tau": np.float64(tau)}
+    for k, v in sd_np(agent).items():
+        if not k.startswith("backbone."):
+            out["init." + k] = v
+    rng = np.random.default_rng(seed_data)
+    torch.manual_seed(seed_fwd)
+    losses = []
+    for k in range(K):
+        s, s2 = fasternet_states(B, seed_data + 10 * k), fasternet_states(B, seed_data + 10 * k + 1)
+        r = rng.normal(size=B).astype(np.float32)
+        d = (rng.uniform(size=B) < 0.2).astype(np.float32)
+        out[f"s{k}"], out[f"s2{k}"], out[f"r{k}"], out[f"d{k}"] = s, s2, r, d
+        vl, gl = agent.por_residual_update(torch.from_numpy(s.copy()), torch.from_numpy(s2.copy()), torch.from_numpy(r),
+                                           torch.from_numpy(d))
+        losses.append((vl, gl))
+    out["losses"] = np.array(losses, dtype=np.float64)
+    for k, v in sd_np(agent).items():
+        if not k.startswith("backbone."):
+            out["final." + k] = v
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: losses={losses}")
+
+
 def gen_per(name, cap=300, N=450, S=6, B=64, seed=17):
     """PrioritizedReplayBuffer (src/porl/buffer/prioritized_replay_buffer.py:7-108): ring of `cap` filled with N > cap
     adds, two samples under random.seed, a priority write-back with a duplicated index, a third sample."""
@@ -669,6 +702,26 @@ def gen_c51(name, S=9, A=5, NA=21, hidden=(48, 40), B=48, K=5, N=400, seed_model
     print(f"{name}: loss={losses}")
 
 
+def gen_iqn_loss(name, B=37, NP=8, NPP=11, kappa=0.7, seed=19):
+    """IQNTrainer.quantile_huber_loss (src/porl/train/iqn_trainer.py:136-149) as an unbound method — the only piece of
+    upstream's IQN trainer that runs (its learn() needs a network class that does not exist in the tree) — with the
+    gradient w.r.t. the current quantiles from autograd."""
+    _stub_cql_imports()
+    from porl.train.iqn_trainer import IQNTrainer
+    g = torch.Generator().manual_seed(seed)
+    cur = torch.randn(B, NP, generator=g).requires_grad_(True)
+    tgt = 1.5 * torch.randn(B, NPP, generator=g)
+    taus = torch.rand(B, NP, generator=g)
+    t = object.__new__(IQNTrainer)
+    t.kappa = kappa
+    td = tgt.unsqueeze(1) - cur.unsqueeze(2)                                  # iqn_trainer.py:127
+    loss = IQNTrainer.quantile_huber_loss(t, td, taus)
+    loss.backward()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), cur=cur.detach().numpy(), target=tgt.numpy(), taus=taus.numpy(),
+                        kappa=np.float64(kappa), loss=np.float64(loss.item()), dcur=cur.grad.numpy())
+    print(f"{name}: loss={loss.item()}")
+
+
 def sub_dict(d, prefix):
     return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
 
@@ -700,6 +753,7 @@ def main():
     # FasterNet costmap encoder (config 5) and SORL with it as backbone
     gen_fasternet("fasternet_b5", B=5)
     gen_sorl_enc("sorl_enc_b6", B=6, K=3)
+    gen_por_enc("por_enc_b4", B=4, K=2)
     # prioritized replay (next row)
     gen_per("per_cap300")
     gen_per_trainer("per_trainer_s12_a5")
@@ -708,6 +762,7 @@ def main():
     gen_bcq("bcq_s10_a6")
     gen_qr("qrdqn_s9_a5_n12")
     gen_c51("c51_s9_a5_n21")
+    gen_iqn_loss("iqn_quantile_huber")
 
 
 if __name__ == "__main__":

@@ -9,7 +9,8 @@ torch math on the device.
 Deliberate differences from the reference (SURVEY.md §8 notes 6):
   * the `pdb.set_trace()` on NLL <= 0 (por.py:104-105) becomes a one-time RuntimeWarning;
   * dead upstream code (`pretrain*`, `por_qlearning_update`, `save/load`) is not provided;
-  * `backbone` must be None (the image-encoder path is not part of this engine yet).
+  * with `backbone=FasterNet(...)` (por.py:46-57,75-79) the encoder runs forward-only: it joins no optimizer
+    upstream, so its backward only fills gradients nobody reads.
 """
 from __future__ import annotations
 
@@ -28,18 +29,20 @@ class POR(IqlAgentBase):
     def __init__(agent, args, max_steps, tau, alpha, backbone=None, device=torch.device('cpu'),
                  value_lr=1e-4, policy_lr=1e-4, discount=0.99, beta=0.005):
         super().__init__()
-        if backbone is not None:
-            raise NotImplementedError("POR(backbone=...) is outside the accelerated path")
         agent.device = torch.device(device)
         agent.backbone = None
+        # with a backbone the heads see its features but the goal policy still predicts the raw next state (por.py:46-57)
+        in_dim = args.state_size if backbone is None else args.feature_dim
+        if backbone is not None:
+            agent.backbone = backbone.to(agent.device)
         # construction order fixes RNG consumption and state_dict order (por.py:36-45)
-        agent.goal_policy = GaussianPolicy(args.state_size, args.state_size,
+        agent.goal_policy = GaussianPolicy(in_dim, args.state_size,
                                            hidden_dim=args.hidden_dim, n_hidden=args.n_hidden)
-        agent.vf = TwinV(args.state_size, layer_norm=args.layer_norm,
+        agent.vf = TwinV(in_dim, layer_norm=args.layer_norm,
                          hidden_dim=args.hidden_dim, n_hidden=args.n_hidden)
         agent.v_target = copy.deepcopy(agent.vf).requires_grad_(False)
         agent._setup_engine(agent.vf, agent.v_target, agent.goal_policy,
-                            obs_dim=args.state_size, pol_out_dim=args.state_size, hidden_dim=args.hidden_dim,
+                            obs_dim=in_dim, pol_out_dim=args.state_size, hidden_dim=args.hidden_dim,
                             n_hidden=args.n_hidden, layer_norm=args.layer_norm, pol_tanh=False, weight_mode=0,
                             device=agent.device, max_batch=int(getattr(args, "max_batch", 0) or
                                                                getattr(args, "batch_size", 0) or 1024))
@@ -56,12 +59,19 @@ class POR(IqlAgentBase):
     def por_residual_update(agent, observations, next_observations, rewards, terminals):
         """One POR gradient step (reference por.py:73-112): IQL value step, EMA target update, then the
         advantage-weighted goal-policy regression on s'.  Returns (v_loss, g_loss) as Python floats."""
-        return agent._full_update(observations, next_observations, rewards, terminals, next_observations,
+        target = next_observations
+        if agent.backbone is not None:          # por.py:75-79: s then s' are encoded; the regression target stays the raw
+            observations = agent.backbone(observations)          # next state (after the encoder's in-place > 8 clamp)
+            next_observations = agent.backbone(next_observations)
+        return agent._full_update(observations, next_observations, rewards, terminals, target,
                                   agent.v_optimizer, agent.goal_policy_optimizer, agent.goal_lr_schedule)
 
     def update_from_replay(agent, replay, batch_size):
         """Extension (not in the reference): one POR step on `batch_size` distinct rows drawn on the device
         from a `porl_amd.buffer.replay_buffer.PackedReplay` — sampling, gather and the update without any
         host-side tensor work.  Same arithmetic as `por_residual_update` on those rows."""
+        if agent.backbone is not None:
+            raise NotImplementedError("update_from_replay draws packed [s | r | s' | d | a] rows for the heads; with a "
+                                      "backbone, gather the rows and call por_residual_update")
         return agent._full_update(None, None, None, None, None, agent.v_optimizer, agent.goal_policy_optimizer,
                                   agent.goal_lr_schedule, replay=replay, batch=batch_size)

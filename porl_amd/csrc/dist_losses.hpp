@@ -80,6 +80,46 @@ __global__ __launch_bounds__(256) void qr_loss_kernel(const QrLossArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// IQN quantile-Huber loss (reference src/porl/train/iqn_trainer.py:136-149, `quantile_huber_loss`):
+//   u_ij = target_j - current_i   (td_target.unsqueeze(1) - current.unsqueeze(2): i over the N' current quantiles,
+//          j over the N'' target quantiles), rho_ij = |tau_i - 1[u_ij < 0]| * Huber_kappa(u_ij), tau = the sampled
+//          fractions of the CURRENT quantiles; loss = mean over (b, i, j).
+// Only this loss head is provided: upstream's IQNTrainer cannot run (it builds IQNNetwork with five positionals for a
+// four-parameter constructor and calls a get_q_values the class does not define, iqn_trainer.py:58-64,89 vs
+// iqn_network.py:10), so its learn() has no reference output to pin against.
+// ---------------------------------------------------------------------------------------------------
+struct IqnLossArgs {
+  const float* cur; const float* target; const float* taus;   // (B, Np), (B, Npp), (B, Np)
+  float* dcur;          // (B, Np)
+  float* row_loss;      // (B,): mean over (i, j) of rho
+  int B, Np, Npp;
+  float kappa, inv_batch;
+};
+
+__global__ __launch_bounds__(256) void iqn_loss_kernel(const IqnLossArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= a.B) return;
+  const float* T = a.target + (long)b * a.Npp;
+  float loss = 0.f;
+  for (int i = lane; i < a.Np; i += 64) {
+    const float th = a.cur[(long)b * a.Np + i], tau = a.taus[(long)b * a.Np + i];
+    float g = 0.f;
+    for (int j = 0; j < a.Npp; ++j) {
+      const float u = T[j] - th, au = fabsf(u);
+      const float w = fabsf(tau - (u < 0.f ? 1.f : 0.f));
+      const bool quad = au <= a.kappa;
+      loss += w * (quad ? 0.5f * u * u : a.kappa * (au - 0.5f * a.kappa));
+      g += w * (quad ? u : (u > 0.f ? a.kappa : -a.kappa));
+    }
+    a.dcur[(long)b * a.Np + i] = -g * a.inv_batch / ((float)a.Np * (float)a.Npp);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
+  if (lane == 0) a.row_loss[b] = loss / ((float)a.Np * (float)a.Npp);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // C51.  logits* are (B, ld) rows holding (A, N) PRE-softmax outputs (the reference's network ends in log_softmax over
 // the atoms, categorical_q_network.py:76-78; the engine's network stops at the Linear layer and the log_softmax lives
 // here, on both sides).

@@ -1736,6 +1736,17 @@ int porl_qr_loss(const float* z_cur, const float* z_next_online, const float* z_
   return PORL_OK;
 }
 
+int porl_iqn_quantile_huber(const float* current, const float* target, const float* taus, int32_t batch, int32_t n_current,
+                            int32_t n_target, float kappa, float* dcurrent_out, float* row_loss, void* stream) {
+  if (!current || !target || !taus || !dcurrent_out || !row_loss || batch < 1 || n_current < 1 || n_target < 1)
+    PORL_FAIL(PORL_ERR_INVALID, "bad arguments");
+  DevGuard _dg(device_of(dcurrent_out));
+  IqnLossArgs a{current, target, taus, dcurrent_out, row_loss, batch, n_current, n_target, kappa, 1.0f / batch};
+  hipLaunchKernelGGL(iqn_loss_kernel, dim3(cdiv(batch, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
 int porl_c51_loss(const float* logits_cur, const float* logits_next_target, int64_t ld, const int64_t* actions,
                   const float* rewards, const float* dones, const float* support, int32_t batch, int32_t n_actions,
                   int32_t n_atoms, float gamma, float v_min, float v_max, float* dlogits_out, float* row_loss, void* stream) {

@@ -91,3 +91,18 @@ def test_c51_projection_conserves_probability_mass():
     for b in range(0, B, 37):
         others = [a for a in range(A) if a != taken[b]]
         assert not d[b, others].any()
+
+
+def test_iqn_quantile_huber_loss_head_matches_reference_golden():
+    """IQNTrainer.quantile_huber_loss (iqn_trainer.py:136-149) and its autograd gradient.  Only this head is pinned:
+    upstream's IQN learn() cannot run (IQNTrainer and IQNNetwork disagree on the constructor and on get_q_values)."""
+    from porl_amd import _native as N
+    z = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "iqn_quantile_huber.npz"))
+    cur, tgt, taus = (torch.from_numpy(z[k]).to(DEV) for k in ("cur", "target", "taus"))
+    B, NP = cur.shape
+    dcur, rl, out = torch.empty_like(cur), torch.empty(B, device=DEV), torch.zeros(1, device=DEV)
+    N.check(N.lib().porl_iqn_quantile_huber(N.ptr(cur), N.ptr(tgt), N.ptr(taus), B, NP, tgt.shape[1], float(z["kappa"]),
+                                            N.ptr(dcur), N.ptr(rl), N.current_stream_ptr(cur)), "porl_iqn_quantile_huber")
+    N.check(N.lib().porl_reduce_mean(N.ptr(rl), B, N.ptr(out), N.current_stream_ptr(cur)), "porl_reduce_mean")
+    np.testing.assert_allclose(float(out), float(z["loss"]), rtol=2e-6)
+    np.testing.assert_allclose(dcur.cpu().numpy(), z["dcur"], atol=2e-8, rtol=2e-5)

@@ -316,3 +316,32 @@ def test_parametrised_costmap_geometry_against_oracle(n_ang, n_dist, B):
     assert rel_err(m(torch.from_numpy(st.copy()).to(DEV)).cpu().numpy(), ref_eval) < REL
     with pytest.raises(RuntimeError):
         m(torch.zeros(2, 362, device=DEV))                    # the state width follows the geometry
+
+
+def test_por_with_encoder_backbone_matches_reference_golden():
+    """POR(backbone=FasterNet) (agent/por.py:46-57,75-79): heads on the 256 features, goal policy regressing the raw
+    362-wide next state; two updates from the reference's seeds (train-mode BatchNorm, DropPath from the CPU stream)."""
+    from types import SimpleNamespace
+    from porl_amd.agent.fasternet import FasterNet
+    from porl_amd.agent.por import POR
+    z, _ = load_golden("por_enc_b4")
+    B, K, H, L, F = (int(v) for v in z["meta"])
+    torch.manual_seed(int(z["seed_model"]))
+    backbone = FasterNet(3, F, max_batch=B)
+    args = SimpleNamespace(state_size=362, feature_dim=F, hidden_dim=H, n_hidden=L, layer_norm=False, action_size=2,
+                           max_batch=B)
+    agent = POR(args, max_steps=50, tau=float(z["tau"]), alpha=float(z["alpha"]), device=DEV, backbone=backbone)
+    sd = agent.state_dict()
+    for k in z.files:
+        if k.startswith("init."):
+            assert np.array_equal(sd[k[5:]].cpu().numpy(), z[k]), k
+    torch.manual_seed(int(z["seed_fwd"]))
+    for k in range(K):
+        t = lambda n: torch.from_numpy(z[f"{n}{k}"].copy()).to(DEV)
+        vl, gl = agent.por_residual_update(t("s"), t("s2"), t("r"), t("d"))
+        np.testing.assert_allclose([vl, gl], z["losses"][k], rtol=5e-5)
+    sd = agent.state_dict()
+    worst = max(float(np.abs(sd[k[6:]].cpu().numpy().astype(np.float64) - z[k]).max()) for k in z.files if k.startswith("final."))
+    assert worst < 2e-5, worst
+    with pytest.raises(NotImplementedError):
+        agent.update_from_replay(None, B)
