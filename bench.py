@@ -172,7 +172,7 @@ def bench_sorl_enc(a):
     Bq, F, Hq, Aq = a.batch or 512, 256, 512, 2
     torch.manual_seed(0)
     n_ang, n_dist = a.angle_bins, a.dist_bins             # 360 x 256 = the reference's image; 84 x 84 = BASELINE's wording
-    backbone = FasterNet(3, F, max_batch=Bq, angle_bins=n_ang, dist_bins=n_dist)
+    backbone = FasterNet(3, F, max_batch=Bq, angle_bins=n_ang, dist_bins=n_dist, compute_dtype=a.enc_dtype)
     args = SimpleNamespace(state_size=n_ang + 2, feature_dim=F, hidden_dim=Hq, n_hidden=2, layer_norm=False, action_size=Aq,
                            max_batch=Bq)
     agent = SORL(args, max_steps=1000, tau=0.9, alpha=3.0, device=dev, backbone=backbone)
@@ -208,19 +208,25 @@ def bench_sorl_enc(a):
     prof = E.prof_read()
     E.prof_enable(False)
     split = {p["name"]: p["total_ms"] / a.steps for p in prof if p["launches"]}
-    gemms = [p for p in prof if p["name"].startswith("gemm_f32_kernel") and p["launches"]]
+    gemms = [p for p in prof if p["name"].startswith(("gemm_f32_kernel", "gemm_bf16_kernel")) and p["launches"]]
     dom = max(gemms, key=lambda p: p["total_ms"])
     ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+    hbm = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9
     enc_flops = 2 * 2 * Bq * 0.86e9 * (n_ang * n_dist) / (360.0 * 256.0)
     out = {"metric": "gradient-steps/sec (SORL update + FasterNet encoder, batch=512)", "value": a.steps / el,
            "unit": "gradient-steps/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic",
+           "dtype": "f32" if a.enc_dtype == "fp32" else "bf16 operands / f32 accumulate (encoder GEMMs), f32 elsewhere",
+           "data": "synthetic",
            "config": {"workload": f"SORL S={n_ang + 2} F={F} H={Hq} B={Bq} + FasterNet(3,{F}) encoder on {n_ang}x{n_dist} costmaps, "
                                   "2 encoder forwards (train-mode BN, DropPath) + value/policy update per step"},
            "algorithmic_tflops": enc_flops * a.steps / el / 1e12,
-           "roofline": dict(bound="mfma", kernel=dom["name"], achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                            frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=None, launches=dom["launches"],
+           "roofline": (dict(bound="mfma", kernel=dom["name"], achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                             frac=ach / PEAK_FP32_MFMA_TFLOPS) if a.enc_dtype == "fp32" else
+                        dict(bound="hbm", kernel=dom["name"], achieved=hbm, peak=8000.0, unit="GB/s", frac=hbm / 8000.0,
+                             algorithmic_bytes_note="rows x (K + N [+ N residual]) x 4 B per product: operands and "
+                                                    "results stay fp32 in HBM, only the multiply is bf16")) |
+                       dict(traffic=None, launches=dom["launches"],
                             avg_launch_us=1e3 * dom["total_ms"] / dom["launches"], all_kernels_ms_per_step=split)}
     if not a.no_cpu_baseline:
         sys.path.insert(0, os.path.join(REPO, "oracle"))
@@ -283,6 +289,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--angle-bins", type=int, default=360, help="sorl_enc: costmap rows (360 = the reference's image)")
     ap.add_argument("--dist-bins", type=int, default=256, help="sorl_enc: costmap columns")
+    ap.add_argument("--enc-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="sorl_enc: operand type of the encoder's 1x1 / merge convolutions (fp32 = reference parity)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",

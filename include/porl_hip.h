@@ -107,14 +107,16 @@ int porl_iql_load_batch_sampled(porl_iql* h, int32_t batch, const float* rows, i
 
 /* Execution mode of the phase calls (default 0).
  *   PORL_IQL_MODE_TWO_SLOTS   : the minibatch staging buffers the policy phase reads (s, policy target, TD target)
- *       exist twice and every porl_iql_load_batch* call flips to the other copy.  The policy phase of update t may
- *       then run on a second stream while update t+1 is loaded and its value phase runs: the caller orders
+ *       exist PORL_IQL_SLOTS times and every porl_iql_load_batch* call moves to the next copy.  The policy phase of
+ *       update t may then run on a second stream while updates t+1 .. t+PORL_IQL_SLOTS-1 are loaded and their value
+ *       phases run (a load must only wait for the policy phase PORL_IQL_SLOTS updates back): the caller orders
  *       value_apply(t) -> policy_backward(t) and policy_apply(t) -> value_apply(t+1) with events (the policy phase
  *       reads the value parameters of update t; everything else it touches is private to it).  The reference runs
  *       the two phases back to back (agent/por.py:81-110); results are identical, only completion order differs.
  *   PORL_IQL_MODE_FOLD_COMBINE: *_backward leaves its split-K slabs / per-block partial sums uncombined and
  *       *_apply combines them inside the Adam launch (one launch less per phase).  grads_* are complete only after
  *       *_apply; a data-parallel caller that all-reduces grads_* between the two calls must not set it. */
+#define PORL_IQL_SLOTS 3           /* copies of the staging buffers in PORL_IQL_MODE_TWO_SLOTS (name kept from ABI 3 drafts) */
 #define PORL_IQL_MODE_TWO_SLOTS 1
 #define PORL_IQL_MODE_FOLD_COMBINE 2
 int porl_iql_set_mode(porl_iql* h, int32_t mode);
@@ -367,6 +369,11 @@ typedef struct porl_enc_cfg {
   int32_t max_batch;
   float mlp_ratio;            /* 2.0 */
   float bn_eps, bn_momentum;  /* nn.BatchNorm2d defaults 1e-5, 0.1 */
+  /* 0 (default, the parity path): fp32 operands on the fp32-input MFMA.  1: the 1x1 / merge convolutions round their
+   * operands to bf16 on the way into LDS and multiply on the bf16 matrix pipe, fp32 accumulate; activations, BatchNorm
+   * statistics, the partial 3x3 conv, the patch embedding and the two head products stay fp32.  The reference has no
+   * bf16 path (fp32 everywhere): results then differ from it by bf16 rounding (tests state the tolerance). */
+  int32_t bf16_operands;
 } porl_enc_cfg;
 
 int porl_enc_create(const porl_enc_cfg* cfg, porl_enc** out);

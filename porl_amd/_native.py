@@ -74,7 +74,7 @@ class QnetVariant(C.Structure):
 class EncCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_ang", "n_dist", "embed_dim", "depth0", "depth1", "n_div",
                                          "feature_dim", "num_classes", "max_batch")] + \
-               [("mlp_ratio", C.c_float), ("bn_eps", C.c_float), ("bn_momentum", C.c_float)]
+               [("mlp_ratio", C.c_float), ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("bf16_operands", C.c_int32)]
 
 
 class ProfEntry(C.Structure):

@@ -200,7 +200,7 @@ class IqlAgentBase(nn.Module):
         eng._ensure_bound()
         eng.set_mode((IqlEngine.MODE_TWO_SLOTS if pipelined else 0) | (IqlEngine.MODE_FOLD_COMBINE if world == 1 else 0))
         if pipelined:
-            eng.wait_slot_free()               # the policy phase of two updates ago used the staging slot loaded next
+            eng.wait_slot_free()               # the policy phase SLOTS updates ago used the staging slot loaded next
         if replay is not None:
             B = eng.load_batch_sampled(replay.rows, batch, replay.seed, replay.draws, replay.act_dim,
                                        self._engine.cfg.weight_mode == 1)
@@ -227,7 +227,7 @@ class IqlAgentBase(nn.Module):
         # ---- policy phase -------------------------------------------------------------------------------------------
         if pipelined:
             main, side = torch.cuda.current_stream(eng.device), eng.side_stream()
-            k = (v_opt.step_count & 1) * 3
+            k = (v_opt.step_count % eng.SLOTS) * 3
             ev_v, ev_f, ev_p = eng.event(k), eng.event(k + 1), eng.event(k + 2)
             ev_v.record(main)
             with torch.cuda.stream(side):
@@ -244,7 +244,7 @@ class IqlAgentBase(nn.Module):
                 ev_p.record(side)
             # the next value Adam waits for ev_f only; readers of the agent (flush) wait for ev_p
             eng._values_read, eng._policy_done = ev_f, ev_p
-            eng._slot_users = (eng._slot_users[1], ev_p)
+            eng._slot_users = eng._slot_users[1:] + [ev_p]
         else:
             eng.policy_backward(hp)
             if self._sharded():

@@ -90,11 +90,16 @@ class FasterNet(nn.Module):
                  patch_size=4, patch_stride=4, patch_size2=2, patch_stride2=2, patch_norm=True, feature_dim=1280,
                  drop_path_rate=0.1, layer_scale_init_value=0, norm_layer='BN', act_layer='RELU', fork_feat=False,
                  init_cfg=None, pretrained=None, pconv_fw_type='split_cat', max_batch=512, angle_bins=None,
-                 dist_bins=None, **kwargs):
+                 dist_bins=None, compute_dtype="fp32", **kwargs):
         super().__init__()
         # costmap geometry: the reference rasterises to 360 x 256 (util/costmap.py:7,12,24) and cannot do otherwise;
         # `angle_bins` / `dist_bins` (multiples of 4) parametrise it, e.g. the 84 x 84 image BASELINE config 5 names.
         # The state then carries angle_bins beams + the 2 goal coordinates.
+        # compute_dtype="bf16": the 1x1 / merge convolutions multiply bf16-rounded operands on the bf16 matrix pipe with
+        # fp32 accumulation (BASELINE config 5's wording).  The reference is fp32 everywhere; "fp32" is the parity path.
+        if compute_dtype not in ("fp32", "bf16"):
+            raise ValueError("compute_dtype must be 'fp32' or 'bf16'")
+        self.compute_dtype = compute_dtype
         if angle_bins is not None:
             self.ANGLE_BINS = int(angle_bins)
         if dist_bins is not None:
@@ -139,7 +144,8 @@ class FasterNet(nn.Module):
         self._lib = N.lib()
         self._cfg = N.EncCfg(self.ANGLE_BINS, self.DIST_BINS, int(embed_dim), int(depths[0]), int(depths[1]),
                              int(n_div), int(feature_dim), int(num_classes), int(max_batch), float(mlp_ratio),
-                             float(self.patch_embed.norm.eps), float(self.patch_embed.norm.momentum))
+                             float(self.patch_embed.norm.eps), float(self.patch_embed.norm.momentum),
+                             int(compute_dtype == "bf16"))
         h = C.c_void_p()
         N.check(self._lib.porl_enc_create(C.byref(self._cfg), C.byref(h)), "porl_enc_create")
         self._h = h

@@ -12,6 +12,7 @@
 
 #include "../../include/porl_hip.h"
 #include "gemm_f32.hpp"
+#include "gemm_bf16.hpp"
 #include "kernels.hpp"
 #include "qnet_fused.hpp"
 #include "per_tree.hpp"
@@ -150,9 +151,10 @@ void layout_mlp(MlpLayout& m, std::vector<TensorInfo>& v, int64_t& cur, int in, 
 }
 
 struct Workspace {
-  // xs / xt / target_v exist twice ("batch slots"): with PORL_IQL_MODE_TWO_SLOTS every load flips the slot, so the
-  // policy phase of update t (on its own stream) can still read its minibatch while update t+1 is being loaded
-  int64_t xs_slot[2], xt_slot[2], target_v_slot[2];
+  // xs / xt / target_v exist PORL_IQL_SLOTS times ("batch slots"): with PORL_IQL_MODE_TWO_SLOTS every load moves to the
+  // next slot, so the policy phase of update t (on its own stream) can still read its minibatch while updates t+1 and
+  // t+2 are being loaded
+  int64_t xs_slot[PORL_IQL_SLOTS], xt_slot[PORL_IQL_SLOTS], target_v_slot[PORL_IQL_SLOTS];
   int64_t xn, rew, term;
   int64_t act_v[2][PORL_MAX_HIDDEN], act_t[2][2], act_p[PORL_MAX_HIDDEN];
   int64_t dz_v[2][2], dz_p[2];
@@ -247,6 +249,30 @@ int launch_group(GemmGroup& g, int tile, hipStream_t s) {
   hipError_t e = launch_gemm_group(tile, g, s);
   if (e != hipSuccess) {
     g_err = std::string("gemm launch: ") + hipGetErrorString(e);
+    return (int)e;
+  }
+  return 0;
+}
+
+// bf16-operand / fp32-accumulate variant (gemm_bf16.hpp): the costmap encoder's opt-in mode
+int launch_group_bf16(GemmGroup& g, int tile, hipStream_t s) {
+  double flops = 0.0, bytes = 0.0;
+  std::string label;
+  if (g_prof.on) {
+    for (int i = 0; i < g.nprob; ++i) {
+      const GemmProb& p = g.p[i];
+      flops += 2.0 * p.M * p.N * p.K;
+      bytes += 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N * (p.resid ? 2.0 : 1.0));
+    }
+    int bm, bn;
+    tile_dims(tile, bm, bn);
+    label = "gemm_bf16_kernel<" + std::to_string(bm) + "," + std::to_string(bn) + "," +
+            (g.p[0].apro != APRO_NONE ? "true" : "false") + ">";
+  }
+  ProfScope ps(label, s, flops, bytes);
+  hipError_t e = launch_gemm_bf16_group(tile, g, s);
+  if (e != hipSuccess) {
+    g_err = std::string("bf16 gemm launch: ") + hipGetErrorString(e);
     return (int)e;
   }
   return 0;
@@ -358,7 +384,7 @@ int porl_iql_create(const porl_iql_cfg* c, porl_iql** out) {
   int64_t o = 0;
   auto take = [&](int64_t n) { int64_t r = o; o += ru4(n); return r; };
   const int64_t BH = (int64_t)B * h->Hp;
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < PORL_IQL_SLOTS; ++k) {
     w.xs_slot[k] = take((int64_t)B * h->Sp); w.xt_slot[k] = take((int64_t)B * h->Dp); w.target_v_slot[k] = take(B);
   }
   w.xn = take((int64_t)B * h->Sp);
@@ -434,7 +460,7 @@ int porl_iql_load_batch(porl_iql* h, int32_t batch, const float* obs, int64_t ob
   if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
   if (!obs || !next_obs || !rew || !term) PORL_FAIL(PORL_ERR_INVALID, "null batch tensor");
   float* W = h->buf.workspace;
-  if (h->mode & PORL_IQL_MODE_TWO_SLOTS) h->slot ^= 1;
+  if (h->mode & PORL_IQL_MODE_TWO_SLOTS) h->slot = (h->slot + 1) % PORL_IQL_SLOTS;
   PackArgs a{};
   a.rows = batch;
   auto job = [&](const float* src, int64_t rs, float* dst, int cols, int ld) {
@@ -543,7 +569,7 @@ int porl_iql_load_batch_sampled(porl_iql* h, int32_t batch, const float* rows, i
   if (row_stride < 2 * (int64_t)S + 2 + act_dim) PORL_FAIL(PORL_ERR_INVALID, "row stride shorter than 2*S+2+A");
   if (target_is_action ? D != act_dim : D != S) PORL_FAIL(PORL_ERR_INVALID, "policy target width mismatch");
   float* W = h->buf.workspace;
-  if (h->mode & PORL_IQL_MODE_TWO_SLOTS) h->slot ^= 1;
+  if (h->mode & PORL_IQL_MODE_TWO_SLOTS) h->slot = (h->slot + 1) % PORL_IQL_SLOTS;
   SampledBatchArgs a{};
   a.rows = rows; a.row_stride = (long)row_stride; a.n_rows = n_rows;
   a.batch = batch; a.S = S; a.A = act_dim; a.D = D; a.Sp = h->Sp; a.Dp = h->Dp;

@@ -26,6 +26,7 @@ def _norm_device(device):
 class IqlEngine:
     GROUP_VF, GROUP_POL = 0, 1
     MODE_TWO_SLOTS, MODE_FOLD_COMBINE = 1, 2          # include/porl_hip.h: PORL_IQL_MODE_*
+    SLOTS = 3                                         # PORL_IQL_SLOTS: copies of the minibatch staging buffers
 
     def __init__(self, obs_dim, pol_out_dim, hidden_dim, n_hidden, layer_norm=False, pol_tanh=False,
                  weight_mode=0, max_batch=1024, device="cpu"):
@@ -45,7 +46,7 @@ class IqlEngine:
         self._side = None
         self._policy_done = None
         self._values_read = None
-        self._slot_users = (None, None)     # policy-done events of the last two pipelined updates (oldest first)
+        self._slot_users = [None] * self.SLOTS         # policy-done events of the last SLOTS pipelined updates, oldest first
         self._events = []
         self._alloc()
 
@@ -65,13 +66,13 @@ class IqlEngine:
     def join(self):
         """Order the current stream behind an outstanding policy phase on the side stream (no host wait)."""
         ev, self._policy_done, self._values_read = self._policy_done, None, None
-        self._slot_users = (None, None)
+        self._slot_users = [None] * self.SLOTS
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
 
     def wait_slot_free(self):
-        """Two staging slots alternate: the slot the next load writes was last read by the policy phase of two
-        pipelined updates ago."""
+        """The staging slots rotate: the slot the next load writes was last read by the policy phase SLOTS pipelined
+        updates ago, i.e. the oldest of the SLOTS events kept here (practically always complete already)."""
         ev = self._slot_users[0]
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
