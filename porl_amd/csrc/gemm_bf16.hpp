@@ -24,7 +24,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // between the rows a half-wave reads).
 template <int BM, int BN, bool APRO>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmGroup g) {
-  constexpr int BK = 32, WM = 2, WN = 2, THREADS = 256;
+  constexpr int BK = 32, WM = 2, WN = 2, THREADS = 256;      // (a 64-column K-tile measured 4 % slower: 52.8 vs 54.9 updates/s)
   constexpr int WTM = BM / WM / 32, WTN = BN / WN / 32;
   constexpr int SKB = BK + 8;                           // LDS row stride in bf16 elements
   constexpr int A_TILE = BM * SKB, B_TILE = BN * SKB;   // bf16 elements
@@ -61,19 +61,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmGroup g) {
 
   const BufRsrc a_rsrc = make_rsrc(P.A, (size_t)M * P.lda * sizeof(float));
   const BufRsrc b_rsrc = make_rsrc(P.B, (size_t)N * P.ldb * sizeof(float));
-  // slot f = t + 256 i: row f / 8, columns (f % 8) * 4 .. +3 of the K-tile
+  // slot f = t + 256 i: row f / (BK/4), columns (f % (BK/4)) * 4 .. +3 of the K-tile
   unsigned a_off[NLA], b_off[NLB];
   int a_lds[NLA], b_lds[NLB], a_k[NLA], b_k[NLB];
 #pragma unroll
   for (int i = 0; i < NLA; ++i) {
-    const int f = t + THREADS * i, kq = f & 7, row = f >> 3;
+    const int f = t + THREADS * i, kq = f % (BK / 4), row = f / (BK / 4);
     a_k[i] = kq * 4;
     a_lds[i] = row * SKB + kq * 4;
     a_off[i] = (m0 + row < M) ? (unsigned)(((size_t)(m0 + row) * P.lda + kq * 4) * sizeof(float)) : BUF_OOB;
   }
 #pragma unroll
   for (int i = 0; i < NLB; ++i) {
-    const int f = t + THREADS * i, kq = f & 7, row = f >> 3;
+    const int f = t + THREADS * i, kq = f % (BK / 4), row = f / (BK / 4);
     b_k[i] = kq * 4;
     b_lds[i] = row * SKB + kq * 4;
     b_off[i] = (n0 + row < N) ? (unsigned)(((size_t)(n0 + row) * P.ldb + kq * 4) * sizeof(float)) : BUF_OOB;
