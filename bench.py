@@ -343,6 +343,8 @@ def main():
     agent = POR(args, max_steps=1000, tau=0.9, alpha=10.0, device=dev)
     agent.async_losses = True                                  # no host sync inside the loop
     agent.pipeline = not a.no_pipeline
+    if os.environ.get("PORL_IQL_FOLD") == "0":                 # A/B: slab combines as separate launches
+        E.tune_set("iql_fold", 0)
     losses = torch.zeros(a.steps + a.warmup, 8, device=dev)    # device-side loss history, one row per update
 
     def one_step(i):

@@ -221,41 +221,44 @@ struct ReduceJob {
   int op;          // 0: sum of the slabs, 1: minimum
   float scale;     // applied to the sum (1 = none)
   long adam_off;   // fused into the Adam launch only: float offset of out[0] inside the parameter group, or -1
+  int width;       // outputs per block: 32 (8 slab lanes) or 4 (64 slab lanes), set by the host from nslab
 };
 constexpr int MAX_REDUCE_JOBS = 12;
 struct ReduceArgs { int njobs; ReduceJob job[MAX_REDUCE_JOBS]; };
 
-// One 32-output chunk of a reduce job by a 256-thread block: lane ty adds slabs ty, ty+8, ... (independent loads in
-// flight), then the 8 partial sums are combined in a fixed order through LDS — latency is nslab/8 loads deep, not
-// nslab.  Returns the combined value in the threads with ty == 0 (valid when i < j.n).
-__device__ __forceinline__ float reduce_chunk(const ReduceJob& j, long i0, float (*sh)[33]) {
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+// One chunk of `j.width` outputs of a reduce job by a 256-thread block: the block is width output columns x
+// (256 / width) slab lanes; lane ty takes slabs ty, ty + L, ... with four loads in flight, then the L partial results
+// are combined in lane order through LDS — the load chain is nslab / (4 L) round trips deep.  width = 32 (8 slab lanes)
+// for short slab lists, 4 (64 lanes) for the long lists of per-block partials (256 loss partials: one round trip).
+// Returns the combined value in the threads with ty == 0 (valid when i < j.n).  Fixed order: deterministic.
+constexpr int REDUCE_LDS_FLOATS = 64 * 5;      // >= L * (width + 1) for (8, 32) and (64, 4)
+__device__ __forceinline__ float reduce_chunk(const ReduceJob& j, long i0, float* sh) {
+  const int W = j.width, L = 256 / W;
+  const int tx = threadIdx.x % W, ty = threadIdx.x / W;
   const long i = i0 + tx;
-  // lane ty takes slabs ty, ty+8, ...: four interleaved running values (4 loads in flight), folded in a fixed order
   const float id = j.op ? INFINITY : 0.f;
   float s0 = id, s1 = id, s2 = id, s3 = id;
   if (i < j.n) {
     const float* p = j.slab + i;
     int k = ty;
-    for (; k + 24 < j.nslab; k += 32) {
-      const float x0 = p[(long)k * j.stride], x1 = p[(long)(k + 8) * j.stride];
-      const float x2 = p[(long)(k + 16) * j.stride], x3 = p[(long)(k + 24) * j.stride];
+    for (; k + 3 * L < j.nslab; k += 4 * L) {
+      const float x0 = p[(long)k * j.stride], x1 = p[(long)(k + L) * j.stride];
+      const float x2 = p[(long)(k + 2 * L) * j.stride], x3 = p[(long)(k + 3 * L) * j.stride];
       if (j.op) { s0 = fminf(s0, x0); s1 = fminf(s1, x1); s2 = fminf(s2, x2); s3 = fminf(s3, x3); }
       else { s0 += x0; s1 += x1; s2 += x2; s3 += x3; }
     }
-    for (; k < j.nslab; k += 8) {
+    for (; k < j.nslab; k += L) {
       const float x = p[(long)k * j.stride];
       s0 = j.op ? fminf(s0, x) : s0 + x;
     }
   }
   const float s = j.op ? fminf(fminf(s0, s1), fminf(s2, s3)) : (s0 + s1) + (s2 + s3);
-  sh[ty][tx] = s;
+  sh[ty * (W + 1) + tx] = s;
   __syncthreads();
   float t = 0.f;
   if (ty == 0 && i < j.n) {
-    t = sh[0][tx];
-#pragma unroll
-    for (int q = 1; q < 8; ++q) t = j.op ? fminf(t, sh[q][tx]) : t + sh[q][tx];
+    t = sh[tx];
+    for (int q = 1; q < L; ++q) t = j.op ? fminf(t, sh[q * (W + 1) + tx]) : t + sh[q * (W + 1) + tx];
     t *= j.scale;
     if (j.bias) t += j.bias[i % j.ncols];
     if (j.act == 1) t = fmaxf(t, 0.f);
@@ -266,10 +269,10 @@ __device__ __forceinline__ float reduce_chunk(const ReduceJob& j, long i0, float
 }
 
 __global__ __launch_bounds__(256) void multi_reduce_kernel(const ReduceArgs a) {
-  __shared__ float sh[8][33];
+  __shared__ float sh[REDUCE_LDS_FLOATS];
   const ReduceJob& j = a.job[blockIdx.y];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (long i0 = (long)blockIdx.x * 32; i0 < j.n; i0 += (long)gridDim.x * 32) {
+  const int W = j.width, tx = threadIdx.x % W, ty = threadIdx.x / W;
+  for (long i0 = (long)blockIdx.x * W; i0 < j.n; i0 += (long)gridDim.x * W) {
     const float t = reduce_chunk(j, i0, sh);
     if (ty == 0 && i0 + tx < j.n) j.out[i0 + tx] = t;
   }
@@ -317,19 +320,19 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
 }
 
 __global__ __launch_bounds__(256) void adam_ema_kernel(const AdamArgs a) {
-  __shared__ float sh[8][33];
+  __shared__ float sh[REDUCE_LDS_FLOATS];
   const AdamScalars s = a.s;
   if ((int)blockIdx.x < a.reduce_blocks) {
-    // ---- reduce block: one 32-output chunk of one job, then Adam on those outputs --------------------------
+    // ---- reduce block: one chunk of one job, then Adam on those outputs --------------------------
     const int rb = blockIdx.x;
     int ji = 0;
 #pragma unroll
     for (int q = 1; q < MAX_REDUCE_JOBS; ++q)
       if (q < a.r.njobs && rb >= a.job_block0[q]) ji = q;
     const ReduceJob& j = a.r.job[ji];
-    const long i0 = (long)(rb - a.job_block0[ji]) * 32;
+    const long i0 = (long)(rb - a.job_block0[ji]) * j.width;
     const float t = reduce_chunk(j, i0, sh);
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tx = threadIdx.x % j.width, ty = threadIdx.x / j.width;
     if (ty == 0 && i0 + tx < j.n) {
       j.out[i0 + tx] = t;
       if (j.adam_off >= 0) {

@@ -103,6 +103,7 @@ struct ProfScope {
 
 unsigned long long* g_qnet_stamps = nullptr;   // porl_tune_set_ptr("qnet_stamps", device buffer of >= 32 u64)
 int g_enc_s2d = 0;           // porl_tune_set("enc_s2d", 1): materialise the 2x2 patches before the merge GEMM (cross-check)
+int g_iql_fold = 1;          // porl_tune_set("iql_fold", 0): porl_iql_step keeps the slab combines as launches of their own (A/B)
 int g_enc_bn_sweep = 0;      // porl_tune_set("enc_bn_sweep", 1): BatchNorm + ReLU of the MLP blocks as a separate sweep (cross-check)
 int g_enc_dense_patch = 0;   // porl_tune_set("enc_dense_patch", 1): rasterise + dense patch embedding (cross-check)
 int g_qnet_fused = 1;     // porl_tune_set("qnet_fused", 0) forces the multi-launch CQL path (A/B measurements)
@@ -294,6 +295,7 @@ void add_reduce(ReduceArgs& r, float* out, const float* slab, long n, long strid
   ReduceJob& j = r.job[r.njobs++];
   j.out = out; j.slab = slab; j.bias = nullptr; j.n = n; j.stride = stride; j.nslab = nslab; j.ncols = 1; j.act = 0;
   j.op = op; j.scale = scale; j.adam_off = -1;
+  j.width = nslab > 64 ? 4 : 32;        // long lists of partials: 64 slab lanes per output instead of 8
 }
 
 int check_ready(const porl_iql* h, bool need_batch) {
@@ -783,7 +785,7 @@ static int adam_launch(float* p, float* g, float* m, float* v, float* tgt, int64
       }
       a.job_block0[a.r.njobs] = reduce_blocks;
       a.r.job[a.r.njobs++] = j;
-      reduce_blocks += (int)((j.n + 31) / 32);
+      reduce_blocks += (int)((j.n + j.width - 1) / j.width);
     }
     a.job_block0[a.r.njobs] = reduce_blocks;
   }
@@ -1019,12 +1021,12 @@ int porl_iql_step(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
   if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
   hipStream_t s = (hipStream_t)stream;
   ReduceArgs fin{};
-  PORL_TRY(value_backward_impl(h, hp, s, &fin));
+  PORL_TRY(value_backward_impl(h, hp, s, g_iql_fold ? &fin : nullptr));
   g_phase = "V8.";
   PORL_TRY(adam_launch(h->buf.params_vf, h->buf.grads_vf, h->buf.adam_m_vf, h->buf.adam_v_vf, h->buf.params_tgt, h->n_vf,
                        hp->value_lr, hp->value_step, hp->adam_beta1, hp->adam_beta2, hp->adam_eps, hp->ema_beta, s, &fin));
   fin = ReduceArgs{};
-  PORL_TRY(policy_backward_impl(h, hp, s, &fin));
+  PORL_TRY(policy_backward_impl(h, hp, s, g_iql_fold ? &fin : nullptr));
   g_phase = "P9.";
   PORL_TRY(adam_launch(h->buf.params_pol, h->buf.grads_pol, h->buf.adam_m_pol, h->buf.adam_v_pol, nullptr, h->n_pol,
                        hp->policy_lr, hp->policy_step, hp->adam_beta1, hp->adam_beta2, hp->adam_eps, 0.0, s, &fin));
@@ -1303,6 +1305,7 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "enc_dense_patch")) { g_enc_dense_patch = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_s2d")) { g_enc_s2d = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_bn_sweep")) { g_enc_bn_sweep = value != 0; return PORL_OK; }
+  if (!strcmp(key, "iql_fold")) { g_iql_fold = value != 0; return PORL_OK; }
   PORL_FAIL(PORL_ERR_INVALID, "unknown tuning key '%s'", key);
 }
 

@@ -16,12 +16,12 @@ p, g, m, v = (torch.randn(n, device=dev) for _ in range(4))
 v = v.abs()
 
 
-TILE = [0]
+TILE = [0, 4096]
 
 
 def big():
-    # one 4096 x 1024 x 1024 problem: 256 tiles of 128x128 launch at once, one per CU (tile 1: 512 blocks of 128x64)
-    E.gemm_f32(0, Abig, Bm[0], 4096, N, K, K, K, Cbig, N, tile=TILE[0])
+    # one M x 1024 x 1024 problem: M = 4096 -> 256 tiles of 128x128, one per CU (tile 1: 512 blocks of 128x64)
+    E.gemm_f32(0, Abig, Bm[0], TILE[1], N, K, K, K, Cbig, N, tile=TILE[0])
 
 
 Abig = torch.randn(4096, K, device=dev)
@@ -46,10 +46,12 @@ def timed(fn, stream, reps=50):
 
 
 sa = torch.cuda.Stream()
-for tile, prio in ((0, 0), (0, -1), (1, 0), (3, 0)):
-    TILE[0] = tile
+for tile, prio, rows, pad in ((0, 0, 4096, 0), (1, 0, 4096, 0), (1, 0, 2048, 0), (3, 0, 1024, 0), (3, 0, 4096, 0), (1, 0, 2048, 60000)):
+    TILE[0], TILE[1] = tile, rows
+    E.tune_set("gemm_lds_pad", pad)
     sb = torch.cuda.Stream(priority=prio)
-    print(f"GEMM tile {('128x128', '128x64', '64x128', '64x64')[tile]}")
+    bm, bn = ((128, 128), (128, 64), (64, 128), (64, 64))[tile]
+    print(f"GEMM tile {bm}x{bn}, M={rows}: {rows // bm * (1024 // bn)} blocks, extra LDS {pad} B")
     print(f"stream B priority {prio}:  GEMM alone {timed(big, sa):7.1f} us   Adam alone {timed(small, sb):7.1f} us")
     # interleaved issue: A then B, 50 times; total wall time vs the sum
     torch.cuda.synchronize()
