@@ -41,11 +41,15 @@ def por_flops_per_sample():
     return 2 * (fwd + bwd)
 
 
-def cpu_baseline(budget_s=15.0):
-    """Numpy-oracle steps/s on the host, same shapes, bounded by wall time.  The BLAS thread count is
-    tuned first (a few trial steps per candidate) so the baseline is not handicapped by oversubscription."""
+def cpu_baseline(budget_s=12.0):
+    """CPU steps/s on the host, same shapes, bounded by wall time: the stronger of (a) eager PyTorch-CPU (MKL,
+    autograd, torch.optim.Adam — how the reference itself runs; oracle/torch_cpu.py) and (b) the numpy oracle
+    (oracle/por_oracle.py), each with its thread count tuned by a few trial steps so that oversubscription does not
+    handicap it.  Both are this repository's restatements ("port"); the reference's files never travel to this box."""
     import numpy as np
+    import torch
     from oracle.por_oracle import PorOracle
+    from oracle.torch_cpu import PorTorchCpu
     from porl_amd.util.init import build_por_state_dict
     from porl_amd.util.synth import make_rows, split_rows
     try:
@@ -53,41 +57,57 @@ def cpu_baseline(budget_s=15.0):
         max_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         threadpool_limits, max_threads = None, os.cpu_count() or 1
-    o = PorOracle(build_por_state_dict(S, H, L, seed=0), S, H, L)
+    sd = build_por_state_dict(S, H, L, seed=0)
     rows = make_rows(8 * B, S, A, seed=0)
+    batches = [split_rows(rows[k * B:(k + 1) * B], S, A)[:4] for k in range(8)]
 
-    def steps(n, k0=0):
-        t0 = time.perf_counter()
-        for j in range(n):
-            k = (k0 + j) % 8
-            s, r, sp, d, _ = split_rows(rows[k * B:(k + 1) * B], S, A)
-            o.por_residual_update(s, sp, r, d)
-        return time.perf_counter() - t0
+    def run(step, budget):
+        step(0)                                                  # warm-up (thread pools, page faults)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            step(n)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget and n >= 3:
+                return n, el
 
-    steps(1)                                                  # warm-up (BLAS threads, page faults)
+    # (a) eager PyTorch on the CPU
+    tb = [tuple(torch.from_numpy(np.ascontiguousarray(x)) for x in (s, sp, r, d)) for s, r, sp, d in batches]
+    ncpu = os.cpu_count() or 1
+    best_tt, best_rate = torch.get_num_threads(), 0.0
+    for tt in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+        torch.set_num_threads(tt)
+        m = PorTorchCpu(sd, S, H, L)
+        n, el = run(lambda i: m.update(*tb[i % 8]), 0.6)
+        if n / el > best_rate:
+            best_tt, best_rate = tt, n / el
+    torch.set_num_threads(best_tt)
+    m = PorTorchCpu(sd, S, H, L)
+    nt, elt = run(lambda i: m.update(*tb[i % 8]), budget_s / 2)
+    cand = [dict(value=nt / elt, cores=int(best_tt), impl="eager PyTorch-CPU (oracle/torch_cpu.py)", n=nt, el=elt)]
+    # (b) numpy oracle
+    o = PorOracle(build_por_state_dict(S, H, L, seed=0), S, H, L)
+    nb = [(s, sp, r, d) for s, r, sp, d in batches]
     best_t, best_rate = max_threads, 0.0
     if threadpool_limits is not None:
         for t in sorted({t for t in (8, 16, 32, 64, max_threads) if t <= max_threads}):
             with threadpool_limits(limits=t):
-                steps(1)
-                rate = 2 / steps(2)
-            if rate > best_rate:
-                best_t, best_rate = t, rate
+                n, el = run(lambda i: o.por_residual_update(*nb[i % 8]), 0.4)
+            if n / el > best_rate:
+                best_t, best_rate = t, n / el
     ctx = threadpool_limits(limits=best_t) if threadpool_limits is not None else None
     try:
-        n, t0 = 0, time.perf_counter()
-        while True:
-            steps(1, n)
-            n += 1
-            el = time.perf_counter() - t0
-            if el >= budget_s and n >= 3:
-                break
+        nn_, eln = run(lambda i: o.por_residual_update(*nb[i % 8]), budget_s / 2)
     finally:
-        if ctx is not None:
-            ctx.restore_original_limits() if hasattr(ctx, "restore_original_limits") else None
-    return dict(value=n / el, unit="gradient-steps/sec", cores=int(best_t), kind="port",
-                sample=f"{n} POR updates (B={B}, H={H}, S={S}) of oracle/por_oracle.py (numpy fp32, BLAS, "
-                       f"{best_t} threads = best of 8..{max_threads}) in {el:.1f} s")
+        if ctx is not None and hasattr(ctx, "restore_original_limits"):
+            ctx.restore_original_limits()
+    cand.append(dict(value=nn_ / eln, cores=int(best_t), impl="numpy oracle (oracle/por_oracle.py)", n=nn_, el=eln))
+    best = max(cand, key=lambda c: c["value"])
+    other = min(cand, key=lambda c: c["value"])
+    return dict(value=best["value"], unit="gradient-steps/sec", cores=best["cores"], kind="port",
+                sample=f"{best['n']} POR updates (B={B}, H={H}, S={S}) of {best['impl']}, {best['cores']} threads (tuned), "
+                       f"in {best['el']:.1f} s; the other port, {other['impl']} on {other['cores']} threads: "
+                       f"{other['value']:.1f} steps/s")
 
 
 def bench_cql(a):
@@ -136,22 +156,42 @@ def bench_cql(a):
                     traffic=None, avg_launch_us=avg_us, launches=dom[0]["launches"], algorithmic_bytes_per_launch=alg_bytes,
                     note="latency-bound: 2.6 MB of compulsory traffic per step, one block per 32 rows walks every layer",
                     all_kernels_us_per_step={p["name"]: 1e3 * p["total_ms"] / a.steps for p in prof if p["launches"]})
-    o = CqlOracle({k: v.detach().cpu().numpy() for k, v in t.q_network.state_dict().items()}, Aq)
+    # CPU baseline: eager PyTorch-CPU restatement (oracle/torch_cpu.py: autograd + torch.optim.Adam, like the reference
+    # runs) incl. numpy's O(N) sampling as buffer/replay_buffer.py:64 does it, threads tuned; the numpy oracle beside it
+    from oracle.torch_cpu import CqlTorchCpu
+    qsd = {k: v.detach().cpu().numpy() for k, v in t.q_network.state_dict().items()}
     rng = np.random.default_rng(0)
-    n, c0 = 0, time.perf_counter()
-    while time.perf_counter() - c0 < 5.0:
+    tst, tac, trw, tns, tdn = (torch.from_numpy(x) for x in (st, ac, rw, ns, dn))
+
+    def torch_rate(budget, threads):
+        torch.set_num_threads(threads)
+        m = CqlTorchCpu(qsd, Aq)
+        n, c0 = 0, time.perf_counter()
+        while time.perf_counter() - c0 < budget:
+            idx = torch.from_numpy(rng.choice(Nq, Bq, replace=False))
+            m.learn(tst[idx], tac[idx], trw[idx], tns[idx], tdn[idx])
+            n += 1
+        return n / (time.perf_counter() - c0), n
+
+    ncpu = os.cpu_count() or 1
+    best_tt = max(sorted({x for x in (1, 4, 8, 16, 32) if x <= ncpu}), key=lambda x: torch_rate(0.5, x)[0])
+    cpu, n = torch_rate(4.0, best_tt)
+    o = CqlOracle(qsd, Aq)
+    n2, c0 = 0, time.perf_counter()
+    while time.perf_counter() - c0 < 2.0:
         idx = rng.choice(Nq, Bq, replace=False)
         o.learn(st[idx], ac[idx], rw[idx], ns[idx], dn[idx])
-        n += 1
-    cpu = n / (time.perf_counter() - c0)
+        n2 += 1
+    cpu_np = n2 / (time.perf_counter() - c0)
     out = {"metric": "gradient-steps/sec (CQL learn, batch=4096)", "value": a.steps / el,
            "unit": "gradient-steps/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "CQL S=60 A=10 B=4096 Q-net 64-128-64, 100k-row device-resident buffer, indices drawn "
                                   "and rows gathered on the device"},
-           "cpu_baseline": {"value": cpu, "unit": "gradient-steps/sec", "kind": "port", "cores": os.cpu_count(),
-                            "sample": f"{n} oracle learn() calls incl. numpy sampling in 5 s"}}
+           "cpu_baseline": {"value": cpu, "unit": "gradient-steps/sec", "kind": "port", "cores": int(best_tt),
+                            "sample": f"{n} learn() steps of the eager PyTorch-CPU restatement (oracle/torch_cpu.py) incl. numpy "
+                                      f"sampling, {best_tt} threads (tuned) in 4 s; numpy oracle: {cpu_np:.1f} steps/s"}}
     if roof:
         out["roofline"] = roof
     print(json.dumps(out), flush=True)
@@ -391,9 +431,10 @@ def main():
         # kernel ALONE on the chip, so this pass runs the same updates back to back on one stream.
         agent.flush()
         agent.pipeline = False
+        psteps = max(a.steps, 100)                 # enough launches for stable per-kernel averages whatever K is
         E.prof_enable(True)
-        for i in range(a.steps):
-            one_step(a.warmup + i)
+        for i in range(psteps):
+            one_step(a.warmup + i % a.steps)
         prof = E.prof_read()
         E.prof_enable(False)
         agent.pipeline = not a.no_pipeline
@@ -426,9 +467,11 @@ def main():
                         frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src,
                         avg_launch_us=avg_ms * 1e3, launches=dom["launches"],
                         flop_per_launch=flops_per_launch,
-                        launches_per_step=sum(p["launches"] for p in prof) / a.steps,
+                        launches_per_step=sum(p["launches"] for p in prof) / psteps,
+                        instrumented_pass="%d updates back to back on one stream (no overlap), HIP events around "
+                                          "every launch (~2.5 us of event overhead inside each figure)" % psteps,
                         # every launch of one update, HIP-event timed on the launch stream (instrumented pass)
-                        step_launches_us={p["name"]: round(1e3 * p["total_ms"] / a.steps, 2) for p in prof if p["launches"]})
+                        step_launches_us={p["name"]: round(1e3 * p["total_ms"] / psteps, 2) for p in prof if p["launches"]})
 
     if rank == 0:
         steps_per_s = a.steps / elapsed

@@ -177,3 +177,32 @@ def test_fasternet_oracle_matches_reference_golden():
             assert np.abs(stats[k] - z["stat_after." + k]).max() < 1e-6, k
     f3 = FO.forward(sd, stats, z["states"].copy(), False)
     assert rel(f3, z["feat_eval_after"]) < 2e-5     # the reference's own fp32 noise: features ~1e-3 here
+
+
+def test_torch_cpu_baseline_restatements_agree_with_the_oracle():
+    """oracle/torch_cpu.py (eager PyTorch-CPU, what bench.py's cpu_baseline leg times) against the numpy oracle that
+    the goldens above pin: same losses over three POR updates and three CQL learn steps."""
+    torch = pytest.importorskip("torch")
+    from oracle.por_oracle import CqlOracle, PorOracle
+    from oracle.torch_cpu import CqlTorchCpu, PorTorchCpu
+    from porl_amd.util.init import build_por_state_dict
+    from porl_amd.util.synth import make_discrete_transitions
+    S, H, L, B = 12, 48, 2, 40
+    sd = build_por_state_dict(S, H, L, seed=3)
+    o, t = PorOracle({k: v.copy() for k, v in sd.items()}, S, H, L), PorTorchCpu(sd, S, H, L)
+    rows = make_rows(3 * B, S, 2, seed=8)
+    for k in range(3):
+        s, r, sp, d, _ = split_rows(rows[k * B:(k + 1) * B], S, 2)
+        want = o.por_residual_update(np.ascontiguousarray(s), np.ascontiguousarray(sp), r, d)
+        got = t.update(*(torch.from_numpy(np.ascontiguousarray(x)) for x in (s, sp, r, d)))
+        np.testing.assert_allclose(got, want, rtol=2e-5)
+    torch.manual_seed(0)
+    from porl_amd.net.q_network import QNetwork
+    qsd = {k: v.numpy().copy() for k, v in QNetwork(10, 5).state_dict().items()}
+    co, ct = CqlOracle({k: v.copy() for k, v in qsd.items()}, 5), CqlTorchCpu(qsd, 5)
+    st, ac, rw, ns, dn = make_discrete_transitions(3 * 64, 10, 5, seed=2)
+    for k in range(3):
+        sl = slice(k * 64, (k + 1) * 64)
+        want = co.learn(st[sl], ac[sl], rw[sl], ns[sl], dn[sl])
+        got = ct.learn(*(torch.from_numpy(x[sl]) for x in (st, ac, rw, ns, dn)))
+        np.testing.assert_allclose(got, want if np.isscalar(want) else want[0], rtol=2e-5)
