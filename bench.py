@@ -385,6 +385,8 @@ def main():
     agent.pipeline = not a.no_pipeline
     if os.environ.get("PORL_IQL_FOLD") == "0":                 # A/B: slab combines as separate launches
         E.tune_set("iql_fold", 0)
+    if os.environ.get("PORL_L0_TILE"):                         # A/B: tile of the K = 60 forward layers
+        E.tune_set("l0_tile", int(os.environ["PORL_L0_TILE"]))
     losses = torch.zeros(a.steps + a.warmup, 8, device=dev)    # device-side loss history, one row per update
 
     def one_step(i):

@@ -103,6 +103,7 @@ struct ProfScope {
 
 unsigned long long* g_qnet_stamps = nullptr;   // porl_tune_set_ptr("qnet_stamps", device buffer of >= 32 u64)
 int g_enc_s2d = 0;           // porl_tune_set("enc_s2d", 1): materialise the 2x2 patches before the merge GEMM (cross-check)
+int g_l0_tile = -1;          // porl_tune_set("l0_tile", t): tile override for the K <= 128 forward layers of the IQL step (A/B)
 int g_iql_fold = 1;          // porl_tune_set("iql_fold", 0): porl_iql_step keeps the slab combines as launches of their own (A/B)
 int g_enc_bn_sweep = 0;      // porl_tune_set("enc_bn_sweep", 1): BatchNorm + ReLU of the MLP blocks as a separate sweep (cross-check)
 int g_enc_dense_patch = 0;   // porl_tune_set("enc_dense_patch", 1): rasterise + dense patch embedding (cross-check)
@@ -332,7 +333,7 @@ int fwd_hidden_layer(porl_iql* h, const FwdNet* nets, int nnets, int B, int K, b
     if (!ln && last && nets[n].headw) { p.headw = nets[n].headw; p.headout = nets[n].headout; }
     g.p[n] = p;
   }
-  const int tile = pick_tile(g);
+  const int tile = (K <= 128 && g_l0_tile >= 0) ? g_l0_tile : pick_tile(g);
   if (parts_out) *parts_out = any_ln ? 1 : head_parts(H, tile);
   PORL_TRY(launch_group(g, tile, s));
   if (any_ln) {
@@ -1306,6 +1307,7 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "enc_s2d")) { g_enc_s2d = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_bn_sweep")) { g_enc_bn_sweep = value != 0; return PORL_OK; }
   if (!strcmp(key, "iql_fold")) { g_iql_fold = value != 0; return PORL_OK; }
+  if (!strcmp(key, "l0_tile")) { g_l0_tile = value; return PORL_OK; }
   PORL_FAIL(PORL_ERR_INVALID, "unknown tuning key '%s'", key);
 }
 
