@@ -3,8 +3,10 @@
 Same constructor, attributes (`goal_policy`, `vf`, `v_target`, `v_optimizer`, `goal_policy_optimizer`,
 `goal_lr_schedule`, `tau`, `alpha`, `discount`, `beta`), `state_dict()` keys and
 `por_residual_update(observations, next_observations, rewards, terminals) -> (v_loss, g_loss)`.
-All arithmetic of the update runs in hand-written gfx950 kernels (porl_amd/csrc); nothing here calls
-torch math on the device.
+All arithmetic of the update (and of `goal_policy(obs)`, `vf.both(obs)`) runs in hand-written gfx950 kernels
+(porl_amd/csrc).  Torch tensor ops on the device remain only in off-path conveniences: `DiagGaussian.log_prob / sample`
+on caller-supplied values (agent/policy.py), the stand-alone EMA on odd-sized tensors (util/util.py), and the replay
+mirror's scatter of newly pushed transitions (buffer/replay_buffer.py).
 
 Deliberate differences from the reference (SURVEY.md §8 notes 6):
   * the `pdb.set_trace()` on NLL <= 0 (por.py:104-105) becomes a one-time RuntimeWarning;

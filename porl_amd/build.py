@@ -22,18 +22,44 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+HASH = OUT + ".srchash"
+
+
+def source_hash():
+    """sha256 over the library's sources (csrc/* and the header), in name order."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def up_to_date():
-    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
+    """The binary is git-ignored and travels by snapshot, so staleness is decided by CONTENT: the hash of the sources it
+    was built from is kept beside it (modification times do not survive a snapshot reliably)."""
+    try:
+        return os.path.exists(OUT) and open(HASH).read().strip() == source_hash()
+    except OSError:
+        return False
 
 
 def build(force=False, verbose=True):
+    sh = source_hash()
     if not force and up_to_date():
+        if verbose:
+            print(f"libporl_hip.so is current (sources sha256 {sh[:16]})", flush=True)
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    with open(HASH, "w") as f:
+        f.write(sh + "\n")
+    if verbose:
+        print(f"built from sources sha256 {sh[:16]}", flush=True)
     return OUT
 
 

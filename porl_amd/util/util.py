@@ -56,8 +56,15 @@ def mlp_spec(seq: nn.Sequential):
 
 
 def update_exponential_moving_average(target, source, alpha):
-    """target <- (1-alpha)*target + alpha*source (reference util/util.py:54-56).  Host/torch version for
-    API parity on small modules; the training step fuses this into the Adam sweep on device."""
+    """target <- (1-alpha)*target + alpha*source (reference util/util.py:54-56), stand-alone (the training step fuses
+    this into the Adam sweep).  Device tensors go through the `porl_ema` kernel when they are 16-byte aligned and a
+    multiple of 4 floats long (every weight matrix and hidden bias of the engines' flat groups); odd-sized leftovers
+    (a scalar head bias) and CPU modules use the two torch ops of the reference."""
+    from .. import engine as E
     with torch.no_grad():
         for t, s in zip(target.parameters(), source.parameters()):
-            t.mul_(1.0 - alpha).add_(s, alpha=alpha)
+            if (t.is_cuda and s.is_cuda and t.is_contiguous() and s.is_contiguous() and t.dtype == torch.float32
+                    and t.numel() % 4 == 0 and t.data_ptr() % 16 == 0 and s.data_ptr() % 16 == 0):
+                E.ema(t, s, alpha)
+            else:
+                t.mul_(1.0 - alpha).add_(s, alpha=alpha)
