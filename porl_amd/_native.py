@@ -184,6 +184,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NativeError(f"{LIB_PATH} not found — run `python -m porl_amd.build` "
                               "(hipcc --offload-arch=gfx950); porl_amd has no CPU fallback")
+        # PyTorch must load ITS HIP runtime first: the wheel bundles libamdhip64.so.7 / libhsa-runtime64 of its own ROCm
+        # build, the library is linked against /opt/rocm's copies with the same SONAMEs, and a process that ends up with
+        # both sets (our library first, torch second) launches into a runtime that sees no device
+        # ("no ROCm-capable device is detected").  Loaded in this order, both share torch's copy.
+        import torch  # noqa: F401
         try:
             l = C.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover
