@@ -83,3 +83,23 @@ def test_errors():
         DeviceDataset(np.zeros((4, 4)), DEV)                    # float64
     with pytest.raises(N.NativeError):
         E.epoch_indices(100, 90, 20, 0, 0, device=DEV)          # walks past the end of the epoch
+
+
+@pytest.mark.parametrize("n", [2 ** 20 + 1, 2 ** 16 + 1, 4 ** 7, 1])
+def test_epoch_permutation_is_exact_just_above_a_power_of_four(n):
+    """The keyed permutation is a Feistel bijection on 4^hb >= n points, cycle-walked into [0, n): just above a power of
+    four the domain is almost 4x the range and many positions need several rounds (the round-1 version stopped after 64
+    rounds and fell back to the identity, which could duplicate a row — ADVICE r1).  Every position of an epoch must map
+    to a distinct row, for several keys."""
+    import torch
+    from porl_amd import engine as E
+    dev = torch.device("cuda")
+    for seed, epoch in ((0, 0), (123456789, 7), (2 ** 63 - 1, 2 ** 31 + 5)):
+        idx = E.epoch_indices(n, 0, n, seed, epoch, device=dev)
+        assert idx.dtype == torch.int64 and idx.numel() == n
+        assert int(idx.min()) == 0 and int(idx.max()) == n - 1
+        assert torch.unique(idx).numel() == n
+    if n > 1:                                               # a window in the middle of an epoch equals that slice
+        whole = E.epoch_indices(n, 0, n, 5, 3, device=dev)
+        part = E.epoch_indices(n, n // 3, min(1000, n - n // 3), 5, 3, device=dev)
+        assert torch.equal(part, whole[n // 3:n // 3 + part.numel()])
