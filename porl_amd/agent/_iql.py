@@ -189,7 +189,9 @@ class IqlAgentBase(nn.Module):
         call returns; update t+1's value phase then runs beside it on the caller's stream.  The only data the two
         share are the value parameters (policy phase t reads the vf of update t), so two events order
         value Adam(t) -> policy phase(t) -> value Adam(t+1); minibatch staging is double-buffered in the engine.
-        Same arithmetic, same results; `flush()` (called by everything that reads the agent) joins the streams.
+        Same arithmetic, same results; `flush()` (called by everything that reads the agent) joins the streams.  The
+        returned statistics view is complete only after `flush()` (or a device synchronisation): g_loss and min NLL of
+        the last update are written by the side stream.
         With a data-parallel group the two gradient exchanges ride on their phase's stream, so the policy-group
         all-reduce and most of the value-group one overlap with the other phase's kernels."""
         eng, ex = self._engine, self._exchange
