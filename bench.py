@@ -385,6 +385,10 @@ def main():
     agent.pipeline = not a.no_pipeline
     if os.environ.get("PORL_IQL_FOLD") == "0":                 # A/B: slab combines as separate launches
         E.tune_set("iql_fold", 0)
+    for i, v in enumerate(os.environ.get("PORL_TILE_MAP", "").split(",")):      # A/B: e.g. "0,1,2,3" = round-1 choice
+        if v.strip():
+            E.tune_set("tile_map%d" % i, int(v))
+            E.tune_set("tile_map_short%d" % i, int(v))
     if os.environ.get("PORL_L0_TILE"):                         # A/B: tile of the K = 60 forward layers
         E.tune_set("l0_tile", int(os.environ["PORL_L0_TILE"]))
     losses = torch.zeros(a.steps + a.warmup, 8, device=dev)    # device-side loss history, one row per update
@@ -455,17 +459,13 @@ def main():
         prof = E.prof_read()
         E.prof_enable(False)
         agent.pipeline = not a.no_pipeline
-        # profile labels are "<launch of the step>:<kernel>"; the roofline is quoted per KERNEL (all its launches)
-        by_kernel = {}
-        for p in prof:
-            if not p["launches"]:
-                continue
-            k = by_kernel.setdefault(p["name"].split(":")[-1].split(".")[-1], dict(launches=0, total_ms=0.0, flops=0.0))
-            for f in ("launches", "total_ms", "flops"):
-                k[f] += p[f]
-        gemms = {n: k for n, k in by_kernel.items() if n.startswith("gemm_f32_kernel")}
+        # profile labels are "<launch of the step>:<kernel>".  The roofline is quoted for the DOMINANT LAUNCH of the
+        # update (the labelled launch with the largest total time: the 4-net hidden-layer forward) — one kernel
+        # instantiation can serve launches of very different shapes, which a per-instantiation average would mix
+        gemms = [p for p in prof if p["launches"] and "gemm_f32_kernel" in p["name"]]
         if gemms:
-            name, dom = max(gemms.items(), key=lambda kv: kv[1]["total_ms"])
+            dom = max(gemms, key=lambda p: p["total_ms"])
+            name = dom["name"].split(":")[-1]
             avg_ms = dom["total_ms"] / dom["launches"]
             flops_per_launch = dom["flops"] / dom["launches"]
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
@@ -480,7 +480,7 @@ def main():
                     break
                 except Exception:
                     pass
-            roof = dict(bound="mfma", kernel=name, achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+            roof = dict(bound="mfma", kernel=name, launch=dom["name"], achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src,
                         avg_launch_us=avg_ms * 1e3, launches=dom["launches"],
                         flop_per_launch=flops_per_launch,

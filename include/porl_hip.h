@@ -119,6 +119,10 @@ int porl_iql_load_batch_sampled(porl_iql* h, int32_t batch, const float* rows, i
 #define PORL_IQL_SLOTS 3           /* copies of the staging buffers in PORL_IQL_MODE_TWO_SLOTS (name kept from ABI 3 drafts) */
 #define PORL_IQL_MODE_TWO_SLOTS 1
 #define PORL_IQL_MODE_FOLD_COMBINE 2
+/*   PORL_IQL_MODE_SHORT_BLOCKS : the big products use 64x64 tiles (3 short blocks per CU) instead of 64x128 / 128x128.
+ *       Alone on the chip they are ~10 % slower, but kernels of a second stream are only placed when blocks retire, so
+ *       this is what lets the policy phase of a pipelined caller actually run beside the value phase. */
+#define PORL_IQL_MODE_SHORT_BLOCKS 4
 int porl_iql_set_mode(porl_iql* h, int32_t mode);
 
 /* Redirect where the next updates write their 3 loss statistics (>= 8 floats, 16-byte aligned): lets a

@@ -200,7 +200,8 @@ class IqlAgentBase(nn.Module):
         if not pipelined:
             eng.join()
         eng._ensure_bound()
-        eng.set_mode((IqlEngine.MODE_TWO_SLOTS if pipelined else 0) | (IqlEngine.MODE_FOLD_COMBINE if world == 1 else 0))
+        eng.set_mode(((IqlEngine.MODE_TWO_SLOTS | IqlEngine.MODE_SHORT_BLOCKS) if pipelined else 0) |
+                     (IqlEngine.MODE_FOLD_COMBINE if world == 1 else 0))
         if pipelined:
             eng.wait_slot_free()               # the policy phase SLOTS updates ago used the staging slot loaded next
         if replay is not None:

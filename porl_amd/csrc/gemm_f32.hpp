@@ -50,7 +50,7 @@ struct GemmProb {
   const float* bias;      // (N,) added before the activation, or null
   const float* mask;      // (M,N) ld=ldmask: C = acc * 1[mask > 0] (ReLU backward), or null
   const float* headw;     // (N,) fused scalar head: headout[part][m] = sum_n C(m,n)*headw[n]
-  float* headout;         // (parts, M) with parts = tiles_n * (waves along N), see head_parts()
+  float* headout;         // (parts, M) with parts = ceil(N / 32): one partial per 32-column group, see head_parts()
   float* colsum;          // !A_KC only: (M,) column sums of A over K (bias gradient); slab s at +s*M
   const float* a_colscale;  // APRO_AFFINE_RELU: (K,) scale
   const float* a_colshift;  // APRO_AFFINE_RELU: (K,) shift
@@ -635,9 +635,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
   float* ctile = lds + wave * (WROWS * CS);
 #pragma unroll
   for (int i = 0; i < WTM; ++i) {
-    float hsum[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) hsum[r] = 0.f;
     const int rbase = m0 + wm * (BM / WM) + i * 32 + 4 * kh;
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
@@ -693,8 +690,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
           o[N] = cq;
         }
       }
+      if (has_head) {
+        // fused scalar head: one partial sum per 32-column group (this MFMA tile), whatever the block tile is, so the
+        // consumer adds the same N/32 partials in the same order under every tile choice (bit-identical results
+        // between the 64x128 and the short-block 64x64 configurations).  Reduce over the 32 columns held by each
+        // half-wave, then one lane per half writes its 16 rows.
+        const int part = (n0 + wn * (BN / WN) + j * 32) >> 5;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hsum[r] += vals[r] * hw;
+        for (int r = 0; r < 16; ++r) {
+          float sh = vals[r] * hw;
+          sh += __shfl_xor(sh, 16);
+          sh += __shfl_xor(sh, 8);
+          sh += __shfl_xor(sh, 4);
+          sh += __shfl_xor(sh, 2);
+          sh += __shfl_xor(sh, 1);
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (li == 0 && row < M && part * 32 < N) P.headout[(size_t)part * M + row] = sh;
+        }
+      }
       if (store_c) {
         if (fast_c) {
           // park the wave's sub-tile in LDS in row-major order; it leaves for memory as 16-byte rows below
@@ -707,27 +720,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
             const int row = rbase + (r & 3) + 8 * (r >> 2);
             if (row < M && col_ok) Cg[(size_t)row * P.ldc + col] = vals[r];
           }
-        }
-      }
-    }
-    if (has_head) {
-      // reduce over the 32 columns held by each half-wave, then one lane per half writes 16 rows
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = hsum[r];
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 8);
-        s += __shfl_xor(s, 4);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 1);
-        hsum[r] = s;
-      }
-      if (li == 0) {
-        const int part = tn * WN + wn;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (row < M) P.headout[(size_t)part * M + row] = hsum[r];
         }
       }
     }
@@ -804,10 +796,10 @@ inline void tile_dims(int tile, int& bm, int& bn) {
   bm = c.bm; bn = c.bn;
 }
 
-// number of partial sums per row written by the fused scalar head
+// number of partial sums per row written by the fused scalar head: one per 32 output columns, for every tile
 inline int head_parts(int N, int tile) {
-  const TileCfg c = tile_cfg(tile);
-  return ((N + c.bn - 1) / c.bn) * c.wn;
+  (void)tile;
+  return (N + 31) / 32;
 }
 constexpr int HEAD_PARTS_PER_64_COLS = 2;   // upper bound: parts <= ceil(N/64) * 2 for every tile config
 

@@ -103,6 +103,16 @@ struct ProfScope {
 
 unsigned long long* g_qnet_stamps = nullptr;   // porl_tune_set_ptr("qnet_stamps", device buffer of >= 32 u64)
 int g_enc_s2d = 0;           // porl_tune_set("enc_s2d", 1): materialise the 2x2 patches before the merge GEMM (cross-check)
+// What pick_tile returns where its occupancy rule selects tile i (porl_tune_set("tile_map<i>", t) / "tile_map_short<i>").
+// Measured on the POR step (gpurun_out/r02, bench.py PORL_TILE_MAP): with two co-resident 64x128 blocks per CU the
+// 4 x 1024^3 launches take 71 instead of 75 us (each block's prologue / C store under the other's MFMA loop), and the
+// 3-net forward / policy backward take 55 / 41 us on 64x64 tiles (768 / 512 blocks = exactly 3 / 2 per CU) instead of
+// 69 / 45 on 128x64 (384 blocks: 1.5 per CU).  SHORT-BLOCK mode (PORL_IQL_MODE_SHORT_BLOCKS, the pipelined update):
+// 64x64 everywhere — alone those launches are slower (77 / 84 us), but a second stream's kernels only get CUs when
+// blocks retire, and 20 us blocks retire often: 2 990 -> 3 110 updates/s.
+int g_tile_map[4] = {TILE_64x128, TILE_64x64, TILE_64x128, TILE_64x64};
+int g_tile_map_short[4] = {TILE_64x64, TILE_64x64, TILE_64x128, TILE_64x64};
+thread_local bool g_short_blocks = false;       // set by the IQL entry points from the handle's mode
 int g_l0_tile = -1;          // porl_tune_set("l0_tile", t): tile override for the K <= 128 forward layers of the IQL step (A/B)
 int g_iql_fold = 1;          // porl_tune_set("iql_fold", 0): porl_iql_step keeps the slab combines as launches of their own (A/B)
 int g_enc_bn_sweep = 0;      // porl_tune_set("enc_bn_sweep", 1): BatchNorm + ReLU of the MLP blocks as a separate sweep (cross-check)
@@ -216,8 +226,8 @@ int pick_tile(const GemmGroup& g) {
   else if (minM <= 64) { cand[nc++] = TILE_64x128; cand[nc++] = TILE_64x64; }
   else { cand[nc++] = TILE_128x128; cand[nc++] = TILE_128x64; cand[nc++] = TILE_64x64; }
   for (int i = 0; i < nc; ++i)
-    if (blocks(cand[i]) >= NUM_CU) return cand[i];
-  return cand[nc - 1];
+    if (blocks(cand[i]) >= NUM_CU) return (g_short_blocks ? g_tile_map_short : g_tile_map)[cand[i]];
+  return (g_short_blocks ? g_tile_map_short : g_tile_map)[cand[nc - 1]];
 }
 
 // split-K factor for an output too small to fill the chip on its own
@@ -303,6 +313,7 @@ int check_ready(const porl_iql* h, bool need_batch) {
   if (!h) PORL_FAIL(PORL_ERR_INVALID, "null engine");
   if (!h->bound) PORL_FAIL(PORL_ERR_UNBOUND, "porl_iql_bind() has not been called");
   if (need_batch && h->batch <= 0) PORL_FAIL(PORL_ERR_INVALID, "no minibatch loaded (porl_iql_load_batch)");
+  g_short_blocks = (h->mode & PORL_IQL_MODE_SHORT_BLOCKS) != 0;
   return 0;
 }
 
@@ -596,7 +607,7 @@ int porl_iql_load_batch_sampled(porl_iql* h, int32_t batch, const float* rows, i
 
 int porl_iql_set_mode(porl_iql* h, int32_t mode) {
   if (!h) PORL_FAIL(PORL_ERR_INVALID, "null engine");
-  if (mode & ~(PORL_IQL_MODE_TWO_SLOTS | PORL_IQL_MODE_FOLD_COMBINE)) PORL_FAIL(PORL_ERR_INVALID, "unknown mode bits");
+  if (mode & ~(PORL_IQL_MODE_TWO_SLOTS | PORL_IQL_MODE_FOLD_COMBINE | PORL_IQL_MODE_SHORT_BLOCKS)) PORL_FAIL(PORL_ERR_INVALID, "unknown mode bits");
   if (h->fin_v_pending || h->fin_p_pending) PORL_FAIL(PORL_ERR_INVALID, "a backward pass is waiting for its apply call");
   h->mode = mode;
   return PORL_OK;
@@ -1166,6 +1177,7 @@ int porl_iql_forward_policy(porl_iql* h, const float* x, int64_t x_rs, int32_t b
 int porl_gemm_f32(int mode, int tile, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
                   int32_t ldb, float* C, int32_t ldc, const float* bias, int act, const float* mask, int32_t ldmask,
                   int splitk, float* slab, void* stream) {
+  g_short_blocks = false;
   if (mode < 0 || mode > 2) PORL_FAIL(PORL_ERR_INVALID, "mode must be 0..2");
   if (M < 1 || N < 1 || K < 0 || !A || !B || !C) PORL_FAIL(PORL_ERR_INVALID, "bad GEMM arguments");
   if (splitk > 1 && !slab) PORL_FAIL(PORL_ERR_INVALID, "splitk > 1 needs a slab buffer");
@@ -1308,6 +1320,14 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "enc_bn_sweep")) { g_enc_bn_sweep = value != 0; return PORL_OK; }
   if (!strcmp(key, "iql_fold")) { g_iql_fold = value != 0; return PORL_OK; }
   if (!strcmp(key, "l0_tile")) { g_l0_tile = value; return PORL_OK; }
+  if (!strncmp(key, "tile_map_short", 14) && key[14] >= '0' && key[14] <= '3' && !key[15] && value >= 0 && value < TILE_COUNT) {
+    g_tile_map_short[key[14] - '0'] = value;
+    return PORL_OK;
+  }
+  if (!strncmp(key, "tile_map", 8) && key[8] >= '0' && key[8] <= '3' && !key[9] && value >= 0 && value < TILE_COUNT) {
+    g_tile_map[key[8] - '0'] = value;
+    return PORL_OK;
+  }
   PORL_FAIL(PORL_ERR_INVALID, "unknown tuning key '%s'", key);
 }
 
@@ -1508,6 +1528,7 @@ int porl_qnet_bind(porl_qnet* h, const porl_qnet_buffers* b) {
 }
 
 static int qnet_ready(const porl_qnet* h, bool need_batch) {
+  g_short_blocks = false;
   if (!h) PORL_FAIL(PORL_ERR_INVALID, "null engine");
   if (!h->bound) PORL_FAIL(PORL_ERR_UNBOUND, "porl_qnet_bind() has not been called");
   if (need_batch && h->batch <= 0) PORL_FAIL(PORL_ERR_INVALID, "no minibatch loaded (porl_qnet_load_batch)");

@@ -25,7 +25,7 @@ def _norm_device(device):
 
 class IqlEngine:
     GROUP_VF, GROUP_POL = 0, 1
-    MODE_TWO_SLOTS, MODE_FOLD_COMBINE = 1, 2          # include/porl_hip.h: PORL_IQL_MODE_*
+    MODE_TWO_SLOTS, MODE_FOLD_COMBINE, MODE_SHORT_BLOCKS = 1, 2, 4     # include/porl_hip.h: PORL_IQL_MODE_*
     SLOTS = 3                                         # PORL_IQL_SLOTS: copies of the minibatch staging buffers
 
     def __init__(self, obs_dim, pol_out_dim, hidden_dim, n_hidden, layer_norm=False, pol_tanh=False,
