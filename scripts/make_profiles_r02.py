@@ -43,11 +43,16 @@ hbm = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)
                 "per-launch averages over all launches of a kernel, counter instances summed.  bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: "
                 "on gfx950 FETCH_SIZE counts 64 B per 128-B request for 16-B/lane reads (MI355X_MICROARCH.md, HBM), so the read "
                 "side is doubled.", "kernels": {}}
+hbm["_note"] += "  Keys are kernel@workgroups (launch shapes kept apart); a plain kernel name repeats the entry of its largest launch."
 for k in fetch:
     if k in write:
-        hbm["kernels"][k.replace("gemm_f32_kernel<", "gemm_f32_kernel<")] = {
+        hbm["kernels"][k] = {
             "fetch_size_kb": fetch[k]["FETCH_SIZE"], "write_size_kb": write[k]["WRITE_SIZE"], "launches": fetch[k]["launches"],
             "hbm_bytes_per_launch": (2 * fetch[k]["FETCH_SIZE"] + write[k]["WRITE_SIZE"]) * 1024}
+for k in list(hbm["kernels"]):                     # plain name -> the shape with the most bytes (the dominant launch)
+    base = k.split("@")[0]
+    if base not in hbm["kernels"] or hbm["kernels"][k]["hbm_bytes_per_launch"] > hbm["kernels"][base]["hbm_bytes_per_launch"]:
+        hbm["kernels"][base] = dict(hbm["kernels"][k], shape=k)
 json.dump(hbm, open(os.path.join(OUT, "r02_hbm_traffic.json"), "w"), indent=1)
 
 m = table(os.path.join(P, "pmc_mfma", "t_results.db"), 2)
