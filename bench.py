@@ -445,6 +445,21 @@ def main():
     if not np.isfinite(lh).all():
         raise SystemExit("non-finite loss in the benchmark run")
 
+    # Not `value`: the same loop again for 1 000 updates.  After any idle the card needs ~10 ms of THIS workload to
+    # settle its clocks (scripts/bench_ramp.py: the first ~20 updates after a sync run 10 % slower, whatever GEMM or
+    # streaming spin-up precedes them), and a K = 20 run also pays the pipeline's fill and drain once; a training job
+    # runs millions of updates, so the sustained rate is reported beside the contract's K-step figure.
+    sustained = None
+    if world == 1 and a.steps < 1000 and os.environ.get("PORL_BENCH_SUSTAINED", "1") != "0":
+        n_s = 1000
+        barrier()
+        ts = time.perf_counter()
+        for i in range(n_s):
+            one_step(a.warmup + i % a.steps)
+        agent.flush()
+        barrier()
+        sustained = n_s / (time.perf_counter() - ts)
+
     roof = None
     if not a.no_roofline:
         # second pass, instrumented: HIP events around every kernel launch on the launch stream.  The timed loop above
@@ -509,6 +524,7 @@ def main():
             "samples_per_sec": steps_per_s * B * world,
             "algorithmic_tflops": steps_per_s * B * world * por_flops_per_sample() / 1e12,
             "final_losses": {"v_loss": float(lh[-1, 0]), "g_loss": float(lh[-1, 1]), "min_nll": float(lh[-1, 2])},
+            "sustained_1000_updates_per_sec": sustained,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "backend": (dist.get_backend() if world > 1 else "none"),
         }
