@@ -118,6 +118,7 @@ int g_iql_fold = 1;          // porl_tune_set("iql_fold", 0): porl_iql_step keep
 int g_enc_bn_sweep = 0;      // porl_tune_set("enc_bn_sweep", 1): BatchNorm + ReLU of the MLP blocks as a separate sweep (cross-check)
 int g_enc_dense_patch = 0;   // porl_tune_set("enc_dense_patch", 1): rasterise + dense patch embedding (cross-check)
 int g_qnet_fused = 1;     // porl_tune_set("qnet_fused", 0) forces the multi-launch CQL path (A/B measurements)
+int g_qnet_two_groups = 1;  // porl_tune_set("qnet_two_groups", 0): the one-group (256-thread) step kernel (A/B, bit-identical)
 
 constexpr int NUM_CU = 256;
 constexpr int SK_MAX = 16;
@@ -1315,6 +1316,7 @@ int porl_tune_set(const char* key, int value) {
   if (!key) PORL_FAIL(PORL_ERR_INVALID, "null key");
   if (!strcmp(key, "gemm_lds_pad")) { gemm_lds_pad() = std::max(0, value); return PORL_OK; }
   if (!strcmp(key, "qnet_fused")) { g_qnet_fused = value != 0; return PORL_OK; }
+  if (!strcmp(key, "qnet_two_groups")) { g_qnet_two_groups = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_dense_patch")) { g_enc_dense_patch = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_s2d")) { g_enc_s2d = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_bn_sweep")) { g_enc_bn_sweep = value != 0; return PORL_OK; }
@@ -1410,6 +1412,7 @@ struct porl_qnet {
   bool fused_ok = false;
   QnetFusedArgs fargs{};
   int fused_lds_bytes = 0;
+  int fused2_lds_w2 = 0, fused2_lds_bytes = 0;       // two-group kernel: offset of the second weight image; 0 = does not fit
   int64_t fslab_stride = 0;
   bool fslab_clean = false;          // alignment gaps of the flat layout are never written: zeroed once
   bool slab_clean = false;           // same for the split-K slabs of the multi-launch path
@@ -1486,6 +1489,10 @@ int porl_qnet_create(const porl_qnet_cfg* c, porl_qnet** out) {
       fa.lds_tmp[1] = off; off += QF_ROWS * (maxw + 4);
       fa.lds_w = off; off += wmax;
       ok = off * (int)sizeof(float) <= QF_MAX_LDS_BYTES;
+      if (ok && (off + wmax) * (int)sizeof(float) <= QF_MAX_LDS_BYTES) {
+        h->fused2_lds_w2 = off;
+        h->fused2_lds_bytes = (off + wmax) * (int)sizeof(float);
+      }
     }
     h->fused_ok = ok;
     h->fused_lds_bytes = off * (int)sizeof(float);
@@ -1611,6 +1618,8 @@ static int qnet_fused_backward(porl_qnet* h, const porl_qnet_hyper* hp, int B, c
   if (!attr_set) {
     PORL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  QF_MAX_LDS_BYTES));
+    PORL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_fused2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 QF_MAX_LDS_BYTES));
     attr_set = true;
   }
   const int nblk = cdiv(B, QF_ROWS);
@@ -1622,7 +1631,10 @@ static int qnet_fused_backward(porl_qnet* h, const porl_qnet_hyper* hp, int B, c
     double macs = 0;
     for (int l = 0; l < a.n_lin; ++l) macs += (double)a.dims[l] * a.dims[l + 1];
     ProfScope ps("qnet_fused_kernel", s, 2.0 * B * macs * 4.0, 8.0 * B * a.dims[0]);
-    hipLaunchKernelGGL(qnet_fused_kernel, dim3(nblk), dim3(256), (size_t)h->fused_lds_bytes, s, a);
+    if (g_qnet_two_groups && h->fused2_lds_w2 > 0)
+      hipLaunchKernelGGL(qnet_fused2_kernel, dim3(nblk), dim3(512), (size_t)h->fused2_lds_bytes, s, a, h->fused2_lds_w2);
+    else
+      hipLaunchKernelGGL(qnet_fused_kernel, dim3(nblk), dim3(256), (size_t)h->fused_lds_bytes, s, a);
     PORL_HIP(hipGetLastError());
   }
   QnetAdam ad{};

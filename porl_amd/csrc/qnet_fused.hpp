@@ -128,6 +128,51 @@ __device__ __forceinline__ void qf_park_w(float* wl, const float4 (&v)[QF_WREGS]
   qf_park_impl(reinterpret_cast<float4*>(wl), v, qf_image4(N, K), t, std::make_integer_sequence<int, QF_WREGS>{});
 }
 
+// NB batches of 16 reduction columns of one 32 x 32 forward tile: two accumulator chains (a chain of dependent
+// 32x32x2 MFMAs issues at half rate), float2 fragments (k, k+1 -> chain 0, chain 1)
+template <int NB>
+__device__ __forceinline__ void qf_fwd_batches(const float* ap, const float* bp, qf_f32x16& acc, qf_f32x16& acc1) {
+  float2 av[NB][4], bv[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      av[b][j] = *reinterpret_cast<const float2*>(ap + 16 * b + 4 * j);
+      bv[b][j] = *reinterpret_cast<const float2*>(bp + 16 * b + 4 * j);
+    }
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b][j].x, bv[b][j].x, acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b][j].y, bv[b][j].y, acc1, 0, 0, 0);
+    }
+}
+
+// NB batches of 16 reduction rows n of one 32 x 32 dgrad tile (see qf_dgrad for the index mapping)
+template <int NB>
+__device__ __forceinline__ void qf_dgrad_batches(const float* ap, const float* bp, int ldw, qf_f32x16& acc, qf_f32x16& acc1) {
+  float4 av[NB][2];
+  float bv[NB][8];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      av[b][i] = *reinterpret_cast<const float4*>(ap + 16 * b + 8 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[b][4 * i + j] = bp[(16 * b + 8 * i + j) * ldw];
+    }
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b][i].x, bv[b][4 * i + 0], acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b][i].y, bv[b][4 * i + 1], acc1, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b][i].z, bv[b][4 * i + 2], acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b][i].w, bv[b][4 * i + 3], acc1, 0, 0, 0);
+    }
+}
+
 // out[32][ldo] = act(in[32][ldi] . Wl^T + bias): wave w computes the 32-column slabs w, w+4, ...
 __device__ __forceinline__ void qf_forward(const float* in, int ldi, const float* wl, int K, int N, const float* bias /* LDS */,
                                            bool relu, float* out, int ldo, int wave, int li, int kh) {
@@ -140,20 +185,23 @@ __device__ __forceinline__ void qf_forward(const float* in, int ldi, const float
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
     const float* ap = in + li * ldi + 2 * kh;
     const float* bp = wl + (tn * 32 + li) * ldw + 2 * kh;
-    // four k-steps per trip: the eight LDS reads are issued together and the MFMAs start as they land (a rolling
-    // one-step prefetch gets folded back by the compiler into read -> wait -> 2 MFMAs, ~2x slower)
-    for (int k0 = 0; k0 < Kp; k0 += 16) {
-      float2 av[4], bv4[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        av[j] = *reinterpret_cast<const float2*>(ap + k0 + 4 * j);
-        bv4[j] = *reinterpret_cast<const float2*>(bp + k0 + 4 * j);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, bv4[j].x, acc, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, bv4[j].y, acc1, 0, 0, 0);
-      }
+    // K runs in batches of 16 columns (8 LDS reads, 8 MFMAs); the loop over the batches is unrolled for the batch
+    // count (1..8), so the compiler sees straight-line code and can request a tile's fragments well ahead of the MFMAs
+    // that use them.  (A run-time loop paid one LDS round trip per batch: 6.5 k cycles for K = 128 against 4.1 k of
+    // matrix work; a hand-rolled prefetch inside a run-time loop made the compiler copy both accumulators every trip.)
+    // (at most four batches = 64 fragment registers in flight: all eight at once spilled)
+    const int nb = Kp >> 4;
+    if (nb > 4) {
+      qf_fwd_batches<4>(ap, bp, acc, acc1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float* ap2 = nb > 4 ? ap + 64 : ap;
+    const float* bp2 = nb > 4 ? bp + 64 : bp;
+    switch (nb > 4 ? nb - 4 : nb) {
+      case 1: qf_fwd_batches<1>(ap2, bp2, acc, acc1); break;
+      case 2: qf_fwd_batches<2>(ap2, bp2, acc, acc1); break;
+      case 3: qf_fwd_batches<3>(ap2, bp2, acc, acc1); break;
+      default: qf_fwd_batches<4>(ap2, bp2, acc, acc1); break;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
@@ -169,6 +217,71 @@ __device__ __forceinline__ void qf_forward(const float* in, int ldi, const float
   }
 }
 
+// One row of the loss stage with the row's Q values in registers: NC float4 chunks cover the A <= 4 NC actions (the
+// padding columns of Q are zero, rows are 16-byte aligned and 36 floats long when A <= 32).  Same arithmetic in the
+// same order as the general branch of qf_loss_rows; dynamic positions (taken action, bootstrap action) are select
+// chains.  (Reading q[j] inside run-time loops cost one LDS round trip per element: ~7 k cycles for 10 actions.)
+template <int NC>
+__device__ __forceinline__ void qf_loss_row_regs(const QnetFusedArgs& a, const float* q, const float* qn, float* dq, int A, int b,
+                                                 int act, float row_rew, float row_done, int am, float& td, float& pen) {
+  constexpr int W = 4 * NC;
+  float qv[W], nv[W];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float4 x = *reinterpret_cast<const float4*>(q + 4 * c);
+    const float4 y4 = *reinterpret_cast<const float4*>(qn + 4 * c);
+    qv[4 * c] = x.x; qv[4 * c + 1] = x.y; qv[4 * c + 2] = x.z; qv[4 * c + 3] = x.w;
+    nv[4 * c] = y4.x; nv[4 * c + 1] = y4.y; nv[4 * c + 2] = y4.z; nv[4 * c + 3] = y4.w;
+  }
+  float mx = -INFINITY, mxn = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < W; ++j) if (j < A) { mx = fmaxf(mx, qv[j]); mxn = fmaxf(mxn, nv[j]); }
+  float se = 0.f;
+#pragma unroll
+  for (int j = 0; j < W; ++j) if (j < A) se += expf(qv[j] - mx);
+  const float lse = mx + logf(se);
+  float qa = 0.f;
+#pragma unroll
+  for (int j = 0; j < W; ++j) qa = j == act ? qv[j] : qa;
+  float qnext = mxn;
+  if (a.double_dqn) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) qnext = j == am ? nv[j] : qnext;
+  }
+  if (a.next_mask) {
+    const float* mk = a.next_mask + (long)b * A;
+    float bestv = nv[0] + (mk[0] - 1.f) * 1e10f;
+    qnext = nv[0];
+#pragma unroll
+    for (int j = 1; j < W; ++j) {
+      if (j < A) {
+        const float v = nv[j] + (mk[j] - 1.f) * 1e10f;
+        if (v > bestv) { bestv = v; qnext = nv[j]; }         // first maximum, like torch.argmax
+      }
+    }
+  }
+  const float y = row_rew + a.gamma * qnext * (1.f - row_done);
+  const float diff = a.td_off ? 0.f : qa - y;
+  float wgt = a.is_w ? a.is_w[b] : 1.f;
+  if (a.w_uniform) wgt *= a.w_uniform[0];
+  td = wgt * (diff * diff);
+  pen = lse - a.log_A - qa;
+  if (a.td_abs) a.td_abs[b] = fabsf(diff);
+  const float ab = a.alpha * a.inv_batch;
+  float g[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    float gj = ab * expf(qv[j] - lse);
+    if (j == act) gj += 2.f * a.inv_batch * wgt * diff - ab;
+    g[j] = j < A ? gj : 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c)        // the whole 36-float row: dL/dQ, then zeros
+    *reinterpret_cast<float4*>(dq + 4 * c) = c < NC ? make_float4(g[4 * (c < NC ? c : 0)], g[4 * (c < NC ? c : 0) + 1],
+                                                                  g[4 * (c < NC ? c : 0) + 2], g[4 * (c < NC ? c : 0) + 3])
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // ---- loss and dL/dQ: one lane per row  (cql_trainer.py:94-118; same arithmetic as cql_loss_kernel).  dq may be
 // the Q buffer itself: a lane reads q[j] before it writes dq[j].  Leaves the block's partial sums in red[0..1].
 __device__ __forceinline__ void qf_loss_rows(const QnetFusedArgs& a, const float* Q, const float* Qn, float* dz, const int* amax,
@@ -180,7 +293,19 @@ __device__ __forceinline__ void qf_loss_rows(const QnetFusedArgs& a, const float
     if (lane < QF_ROWS) {
       const int b = row0 + lane;
       float* dq = dz + lane * ldq;
-      if (b < a.B) {
+      if (b < a.B && A <= 32) {
+        const float* q = Q + lane * ldq;
+        const float* qn = Qn + lane * ldq;
+        const int am = a.double_dqn ? amax[lane] : 0;
+        switch ((A + 3) >> 2) {
+          case 1: qf_loss_row_regs<1>(a, q, qn, dq, A, b, row_act, row_rew, row_done, am, td, pen); break;
+          case 2: qf_loss_row_regs<2>(a, q, qn, dq, A, b, row_act, row_rew, row_done, am, td, pen); break;
+          case 3: qf_loss_row_regs<3>(a, q, qn, dq, A, b, row_act, row_rew, row_done, am, td, pen); break;
+          case 4: qf_loss_row_regs<4>(a, q, qn, dq, A, b, row_act, row_rew, row_done, am, td, pen); break;
+          case 5: case 6: qf_loss_row_regs<6>(a, q, qn, dq, A, b, row_act, row_rew, row_done, am, td, pen); break;
+          default: qf_loss_row_regs<8>(a, q, qn, dq, A, b, row_act, row_rew, row_done, am, td, pen); break;
+        }
+      } else if (b < a.B) {
         const float* q = Q + lane * ldq;
         const float* qn = Qn + lane * ldq;
         float mx = -INFINITY, mxn = -INFINITY;
@@ -225,78 +350,90 @@ __device__ __forceinline__ void qf_loss_rows(const QnetFusedArgs& a, const float
   }
 }
 
-// dW_l = dZ^T . in over the block's 32 rows (32 x 32 tiles of (n, k), round-robin over the waves) and db_l = column
-// sums of dZ, written to the block's slab in the flat parameter layout
-__device__ __forceinline__ void qf_wgrad(const QnetFusedArgs& a, int l, const float* dz, const float* in, float* slab, int wave,
-                                         int li, int kh, int t) {
+// dW_l = dZ^T . in over the block's 32 rows (32 x 32 tiles of (n, k), dealt over `nw` waves, wave id `w`) and db_l =
+// column sums of dZ (over `nt` threads, thread id `t`), written to the block's slab in the flat parameter layout.
+// A tile's 32 + 32 fragment values are all requested before its 16 MFMAs (one LDS round trip per tile, not four).
+__device__ __forceinline__ void qf_wgrad_n(const QnetFusedArgs& a, int l, const float* dz, const float* in, float* slab, int w,
+                                           int nw, int li, int kh, int t, int nt) {
   const int N = a.dims[l + 1], K = a.dims[l];
   const int lddz = qf_r32(N) + 4, ldin = qf_r32(K) + 4;
   const int tiles_n = qf_r32(N) / 32, tiles_k = qf_r32(K) / 32;
-  for (int tile = wave; tile < tiles_n * tiles_k; tile += 4) {
+  // (hoisted: left inside the predicated stores, a.w_off[l] was re-read from the kernel arguments — a scalar load and
+  //  s_waitcnt lgkmcnt(0) — before each of a tile's 16 stores: ~8 k cycles per layer)
+  float* const wslab = slab + a.w_off[l];
+  float* const bslab = slab + a.b_off[l];
+  const int ldp = qf_rk(K) + 4;
+  for (int tile = w; tile < tiles_n * tiles_k; tile += nw) {
     const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
     qf_f32x16 acc, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
-    for (int s2 = 0; s2 < QF_ROWS / 2; s2 += 4) {
-      float av[4], bv4[4];
+    float av[QF_ROWS / 2], bv4[QF_ROWS / 2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = 2 * (s2 + j) + kh;
-        av[j] = dz[row * lddz + tn * 32 + li];
-        bv4[j] = in[row * ldin + tk * 32 + li];
-      }
+    for (int j = 0; j < QF_ROWS / 2; ++j) {
+      const int row = 2 * j + kh;
+      av[j] = dz[row * lddz + tn * 32 + li];
+      bv4[j] = in[row * ldin + tk * 32 + li];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 4; j += 2) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv4[j], acc, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j + 1], bv4[j + 1], acc1, 0, 0, 0);
-      }
+    for (int j = 0; j < QF_ROWS / 2; j += 2) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv4[j], acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j + 1], bv4[j + 1], acc1, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
     const int k = tk * 32 + li;
+    float* const wp = wslab + (tn * 32 + 4 * kh) * ldp + k;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int n = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (n < N && k < K) slab[a.w_off[l] + (long)n * (qf_rk(K) + 4) + k] = acc[r];
+      const int dn = (r & 3) + 8 * (r >> 2);
+      if (tn * 32 + 4 * kh + dn < N && k < K) wp[dn * ldp] = acc[r];
     }
   }
-  for (int n = t; n < N; n += 256) {
+  for (int n = t; n < N; n += nt) {
+    float v[QF_ROWS];
+#pragma unroll
+    for (int r = 0; r < QF_ROWS; ++r) v[r] = dz[r * lddz + n];
     float s = 0.f;
-    for (int r = 0; r < QF_ROWS; ++r) s += dz[r * lddz + n];
-    slab[a.b_off[l] + n] = s;
+#pragma unroll
+    for (int r = 0; r < QF_ROWS; ++r) s += v[r];
+    bslab[n] = s;
   }
 }
 
-// dZ_{l-1} = (dZ . W_l) * 1[in > 0]: 32-column slabs of K over the waves.  dzp may be `in` itself (the activation
-// is dead afterwards): a lane reads in[row][col] right before it writes dzp[row][col].
+// dZ_{l-1} = (dZ . W_l) * 1[in > 0]: 32-column slabs of K over the waves.  dzp must not overlap `in`.
+// The reduction runs over n in batches of 16: the half-wave kh takes n0 + 8 i + 4 kh + j (i < 2, j < 4), so its dZ
+// values are two 16-byte reads of its row (the k index of v_mfma_f32_32x32x2_f32 only has to pair A with B), its
+// weights eight 4-byte reads of consecutive columns.
 __device__ __forceinline__ void qf_dgrad(const float* dz, int lddz, const float* wl, int N, int K, const float* in, int ldin,
                                          float* dzp, int wave, int li, int kh) {
-  const int ldw = qf_rk(K) + 4, tiles_k = qf_r32(K) / 32;
+  const int ldw = qf_rk(K) + 4, tiles_k = qf_r32(K) / 32, Np = qf_r32(N);
   for (int tk = wave; tk < tiles_k; tk += 4) {
     qf_f32x16 acc, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
-    for (int n0 = 0; n0 < qf_r32(N); n0 += 8) {
-      float av[4], bv4[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + 2 * j + kh;
-        av[j] = dz[li * lddz + n];
-        bv4[j] = wl[n * ldw + tk * 32 + li];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j += 2) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv4[j], acc, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j + 1], bv4[j + 1], acc1, 0, 0, 0);
-      }
+    const float* ap = dz + li * lddz + 4 * kh;
+    const float* bp = wl + 4 * kh * ldw + tk * 32 + li;
+    // (the weight image has round32(N) rows and dZ rows are zero up to round32(N) columns: Np is a multiple of 32;
+    //  unrolled per batch count like the forward tiles)
+    for (int n0 = 0; n0 < Np; n0 += 64) {
+      if (Np - n0 >= 64) qf_dgrad_batches<4>(ap + n0, bp + n0 * ldw, ldw, acc, acc1);
+      else qf_dgrad_batches<2>(ap + n0, bp + n0 * ldw, ldw, acc, acc1);
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
     const int col = tk * 32 + li;
+    // the 16 activations first, then the 16 stores: interleaved, every read waited for the store before it (the
+    // compiler must assume dzp aliases in) — 16 LDS round trips, ~3 k cycles per layer
+    float act[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) act[r] = in[((r & 3) + 8 * (r >> 2) + 4 * kh) * ldin + col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-      dzp[row * ldin + col] = (col < K && in[row * ldin + col] > 0.f) ? acc[r] : 0.f;
+      dzp[row * ldin + col] = (col < K && act[r] > 0.f) ? acc[r] : 0.f;
     }
   }
 }
@@ -400,7 +537,7 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
     const int lddz = qf_r32(N) + 4, ldin = qf_r32(K) + 4;
     const float* in = qf_lds + a.lds_act[l];
     if (l > 0) park(n0 + 3 * L + 2 - l);                                   // for dZ_{l-1}; nobody reads wl right now
-    qf_wgrad(a, l, dz, in, slab, wave, li, kh, t);
+    qf_wgrad_n(a, l, dz, in, slab, wave, 4, li, kh, t, 256);
     stamp();
     if (l == 0) break;
     qf_barrier();                                                  // wl is parked
@@ -412,6 +549,211 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
     dz = dzp;
     stamp();
   }
+}
+
+// ---- two wave groups per block -----------------------------------------------------------------------------------
+// The one-group kernel above is a chain of ~3L+3 dependent stages (park a layer, barrier, 32-row MFMA chains, barrier),
+// each worth 5-9 k cycles of latency whatever the arithmetic.  Two of its chains are independent of each other:
+//   * the target network on s' and the online network on s (cql_trainer.py:94 and :99-101), and
+//   * dW_l = dZ_l^T . in_l and dZ_{l-1} = (dZ_l . W_l) * 1[in_l > 0] of one layer.
+// This kernel runs them side by side on 8 waves: group 0 (waves 0-3) walks the target net, then the dgrad chain with
+// the weight staging that chain needs; group 1 (waves 4-7) walks the online net, then the wgrad tiles.  Both groups
+// execute the same barrier sequence (the layer shapes are the same), so the shared s_barrier costs nothing extra.
+// In the backward pass nobody reads forward weights any more, so the two weight buffers alternate: W_{l-1} is parked
+// while layer l is differentiated, and a layer costs ONE barrier.  Same arithmetic, same summation orders: results are
+// bit-identical to the one-group kernel (tests/test_cql_gpu.py).  Needs a second weight image in LDS (config 3:
+// 151 KB); the host falls back to the one-group kernel when that does not fit.
+// One input (32 rows) of a wave group, in three steps so that the caller can put independent work between the two
+// dependent round trips: (1) the source row numbers, (2) the elements, (3) the LDS stores.
+// Every slot is straight-line code: a slot past the image re-reads element 0 and is dropped at the store.  (With a
+// branch per slot — `if (u * 256 < total)`, `idx ? idx[b] : b` — the compiler closed every slot with s_waitcnt
+// vmcnt(0): nine dependent round trips to HBM at kernel entry instead of two, ~12 k cycles.)
+struct QfInput { long row[QF_XREGS]; float v[QF_XREGS]; };
+__device__ __forceinline__ void qf_input_rows(QfInput& in, int ld, const int64_t* idx, int row0, int B, int t) {
+  const int total = QF_ROWS * ld;
+  const float inv_ld = 1.0f / (float)ld;
+  if (idx) {
+#pragma unroll
+    for (int u = 0; u < QF_XREGS; ++u) {
+      const int i = u * 256 + t;
+      const int b = row0 + qf_div(i < total ? i : 0, inv_ld);
+      in.row[u] = idx[b < B ? b : 0];
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < QF_XREGS; ++u) {
+      const int i = u * 256 + t;
+      in.row[u] = row0 + qf_div(i < total ? i : 0, inv_ld);
+    }
+  }
+}
+__device__ __forceinline__ void qf_input_load(QfInput& in, int ld, const float* src, long rs, int row0, int B, int cols, int t) {
+  const int total = QF_ROWS * ld;
+  const float inv_ld = 1.0f / (float)ld;
+#pragma unroll
+  for (int u = 0; u < QF_XREGS; ++u) {
+    const int i = u * 256 + t;
+    const int r = qf_div(i < total ? i : 0, inv_ld), c = i - r * ld;
+    const bool ok = i < total && row0 + r < B && c < cols;
+    const float x = src[ok ? in.row[u] * rs + c : 0L];
+    in.v[u] = ok ? x : 0.f;
+  }
+}
+__device__ __forceinline__ void qf_input_store(const QfInput& in, float* dst, int ld, int t) {
+  const int total = QF_ROWS * ld;
+#pragma unroll
+  for (int u = 0; u < QF_XREGS; ++u) {
+    const int i = u * 256 + t;
+    if (i < total) dst[i] = in.v[u];
+  }
+}
+
+__global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a, int lds_w2) {
+  extern __shared__ float qf_lds[];
+  __shared__ float red[2];
+  __shared__ int amax[QF_ROWS];
+  const int t = threadIdx.x, grp = t >> 8, tg = t & 255, lane = t & 63, li = lane & 31, kh = lane >> 5;
+  // A block's waves are dealt to the SIMDs in the order 0,2,1,3,0,2,1,3: wave w of group 0 and wave w of group 1 share
+  // a SIMD.  Layers with fewer than four 32-column slabs occupy waves 0.. only, so group 1 numbers its waves from 2:
+  // the busy waves of the two groups then sit on different SIMDs.
+  const int wave = (((t >> 6) & 3) + 2 * grp) & 3;
+  const int row0 = blockIdx.x * QF_ROWS;
+  const int L = a.n_lin - 1;
+  float* const wbuf0 = qf_lds + a.lds_w;
+  float* const wbuf1 = qf_lds + lds_w2;
+  float* wl = grp ? wbuf1 : wbuf0;                   // the group's forward weight buffer
+  float* X = qf_lds + a.lds_act[0];
+  float* Xn = qf_lds + a.lds_tmp[1];
+  const int ldx = qf_r32(a.dims[0]) + 4;
+  const int dd = a.double_dqn;
+
+  int n_stamp = 0;
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if (a.stamps && blockIdx.x == 0 && t == 0) a.stamps[n_stamp++] = __builtin_amdgcn_s_memtime();
+  };
+  stamp();
+  int n_stamp2 = 0;                                  // group 1's own timeline (its wave 0), entries 32..
+  auto stamp2 = [&]() __attribute__((always_inline)) {
+    if (a.stamps && blockIdx.x == 0 && t == 256) a.stamps[32 + n_stamp2++] = __builtin_amdgcn_s_memtime();
+  };
+  // Weight staging by LDS-DMA (global_load_lds_dwordx4): the parameter group stores every layer as its LDS image, so a
+  // layer is a linear copy of 1 KiB pieces (wave-uniform LDS base + lane x 16 B) that needs no registers and no store
+  // pass.  (Register staging — 17 float4 per thread fetched a stage ahead, parked with ds_write_b128 — cost ~2.9 k
+  // cycles per layer to park, ~1.7 k to issue and another ~2 k of barrier skew: scripts/bench_cql_prof.py.)
+  // Weight stages of a group, in the order it uses them:
+  //   group 0: target layers 0..L, then the online layers L..1 (dgrad)
+  //   group 1: [Double DQN: online layers 0..L for the pass over s',] online layers 0..L
+  const int n_lead = dd ? L + 1 : 0;
+  auto dma = [&](int j, float* dst) __attribute__((always_inline)) {
+    int l;
+    const float* P = a.params;
+    if (grp) l = j < n_lead ? j : j - n_lead;
+    else if (j <= L) { l = j; P = a.params_tgt; }
+    else l = 2 * L + 1 - j;
+    const float* img = P + a.w_off[l];
+    const int total4 = qf_image4(a.dims[l + 1], a.dims[l]);
+    // Written as an asm statement: the compiler orders every later LDS read behind a pending
+    // __builtin_amdgcn_global_load_lds with s_waitcnt vmcnt(0) (it cannot tell the buffers apart), which would expose a
+    // piece's whole flight time in the dgrad chain and in the loss stage.  The waits are placed by hand (barrier_vm).
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)dst;
+    for (int base = (tg >> 6) * 64; base < total4; base += 256) {            // wave-uniform
+      const int i = base + lane;
+      if (i < total4) {
+        unsigned keep;
+        const float* gsrc = img + 4 * i;
+        const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds0 + 16u * (unsigned)base);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+      }
+    }
+  };
+  // barrier that also retires this wave's LDS-DMA pieces (they count in vmcnt)
+  auto barrier_vm = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // The longest dependent chain at entry is index -> row -> LDS: the row numbers are requested first, the first weight
+  // image and the loss stage's per-row scalars (lanes 0..31 of wave 0; see the one-group kernel) while they are in flight.
+  // Group 0 gathers s' (for the target net), group 1 gathers s.
+  QfInput xin;
+  qf_input_rows(xin, ldx, a.idx, row0, a.B, tg);
+  const int my_row = row0 + (t < QF_ROWS ? t : 0);
+  const long my_src = my_row < a.B ? (a.idx ? a.idx[my_row] : (long)my_row) : 0L;
+  dma(0, wl);
+  qf_input_load(xin, ldx, grp ? a.states : a.next_states, grp ? a.s_rs : a.n_rs, row0, a.B, a.dims[0], tg);
+  const int row_act = (int)a.actions[my_src];
+  const float row_rew = a.rew[my_src], row_done = a.done[my_src];
+  qf_input_store(xin, grp ? X : Xn, ldx, tg);
+  stamp();
+
+  // ---- forward: role 1 = target net on s' (ping-pong in tmp), 2 = online net on s' (Double DQN: argmax kept),
+  //      3 = online net on s (activations kept), 0 = idle (barriers only) -----------------------------------------------
+  int stage_no = 0;
+  for (int phase = dd ? 0 : 1; phase < 2; ++phase) {
+    const int role = phase == 0 ? (grp ? 2 : 1) : (grp ? 3 : (dd ? 0 : 1));
+    for (int l = 0; l <= L; ++l) {
+      if (role && stage_no > 0) dma(stage_no, wl);       // (stage 0 was requested at entry; wl is free: barrier below)
+      stamp();
+      barrier_vm();
+      stamp();
+      if (role) {
+        ++stage_no;
+        const float* in = l == 0 ? (role == 3 ? X : Xn) : (role == 1 ? qf_lds + a.lds_tmp[(l - 1) & 1] : qf_lds + a.lds_act[l]);
+        float* out = role == 1 ? qf_lds + a.lds_tmp[l & 1] : qf_lds + a.lds_act[l + 1];
+        const float* bl = wl + qf_r32(a.dims[l + 1]) * (qf_rk(a.dims[l]) + 4);
+        qf_forward(in, qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L, out, qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
+        stamp();
+      }
+      qf_barrier();
+      stamp();
+    }
+    if (role == 2 && tg < QF_ROWS) {
+      const float* q = qf_lds + a.lds_act[L + 1] + tg * (qf_r32(a.dims[L + 1]) + 4);
+      int best = 0;
+      for (int j = 1; j < a.dims[L + 1]; ++j) best = q[j] > q[best] ? j : best;     // first maximum, like torch.max
+      amax[tg] = best;
+    }
+  }
+  const float* Qn = qf_lds + a.lds_tmp[L & 1];
+  float* dz = qf_lds + a.lds_tmp[(L + 1) & 1];
+
+  // ---- loss (wave 0 of group 0) ---------------------------------------------------------------------------------------
+  // The dgrad chain needs the ONLINE weights W_L .. W_1.  W_L is what group 1 staged last, so it is already in wbuf1;
+  // the two buffers alternate from there (bsel), and W_{L-1} is requested into wbuf0 now — every wave is past the last
+  // forward barrier, so group 0's forward buffer is dead — and lands while the loss is computed.
+  auto bsel = [&](int l) __attribute__((always_inline)) { return ((L - l) & 1) ? wbuf0 : wbuf1; };
+  if (grp == 0 && L > 1) dma(L + 2, bsel(L - 1));
+  if (grp == 0) qf_loss_rows(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, row_act, row_rew, row_done, row0, lane, wave, red);
+  if (grp == 0) barrier_vm(); else qf_barrier();
+  if (t == 0) { a.part_td[blockIdx.x] = red[0]; a.part_pen[blockIdx.x] = red[1]; }
+  stamp();
+
+  // ---- backward, top down: group 0 = dZ chain (+ requests the weights two layers down), group 1 = dW / db ---------
+  // While layer l is differentiated from bsel(l), W_{l-1} is on its way into the other buffer: requested at the top of
+  // this iteration (that buffer held W_{l+1}, which every wave is done with since the last barrier), waited for at the
+  // closing barrier.
+  // Only group 0 waits on vmcnt at the closing barrier: group 1's counter holds its slab stores, which nobody reads here.
+  float* slab = a.slab + (long)blockIdx.x * a.slab_stride;
+  for (int l = L; l >= 1; --l) {
+    const int N = a.dims[l + 1], K = a.dims[l];
+    const int lddz = qf_r32(N) + 4, ldin = qf_r32(K) + 4;
+    const float* in = qf_lds + a.lds_act[l];
+    float* dzp = qf_lds + a.lds_tmp[l & 1];                           // dZ_l lives in tmp[(l + 1) & 1]
+    if (grp == 0) {
+      if (l < L && l > 1) dma(2 * L + 2 - l, bsel(l - 1));            // W_{l-1} into the buffer dgrad(l + 1) is done with
+      stamp();
+      qf_dgrad(dz, lddz, bsel(l), N, K, in, ldin, dzp, wave, li, kh);
+      stamp();
+      barrier_vm();
+    } else {
+      stamp2();
+      qf_wgrad_n(a, l, dz, in, slab, wave, 4, li, kh, tg, 256);
+      stamp2();
+      qf_barrier();
+    }
+    dz = dzp;
+    stamp();
+  }
+  // layer 0 has no dZ to pass on: all eight waves share its dW tiles
+  qf_wgrad_n(a, 0, dz, qf_lds + a.lds_act[0], slab, (t >> 6), 8, li, kh, t, 512);
+  stamp();
 }
 
 // optional Adam step fused into the gradient reduction (p == null: off)

@@ -34,7 +34,12 @@ buf = torch.zeros(64, dtype=torch.int64, device=dev)
 N.check(N.lib().porl_tune_set_ptr(b"qnet_stamps", N.ptr(buf)))
 t.learn_device_sampled(); torch.cuda.synchronize()
 N.check(N.lib().porl_tune_set_ptr(b"qnet_stamps", None))
-s = buf.cpu().numpy(); s = s[s != 0]
+raw = buf.cpu().numpy()
+s = raw[:32]; s = s[s != 0]
 d = (s[1:] - s[:-1])
 print("   raw deltas:", [int(x) for x in d])
 print("   total", int(s[-1] - s[0]))
+g1 = raw[32:]; g1 = g1[g1 != 0]
+if len(g1):
+    print("   group 1 (relative to kernel entry):", [int(x - s[0]) for x in g1])
+    print("   group 0 cumulative:", [int(x - s[0]) for x in s])

@@ -176,6 +176,51 @@ def test_one_launch_gradients_on_odd_shapes(S, A, B, hidden):
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-6, atol=5e-8)   # (penalty = lse - ln A - q: O(1) terms cancel)
 
 
+@pytest.mark.parametrize("S,A,B,hidden", [(60, 10, 4096, (64, 128, 64)), (17, 3, 33, (32, 96)), (5, 2, 1, (7,)), (12, 5, 100, (64,))])
+@pytest.mark.parametrize("variant", ["cql", "double_dqn", "bcq_mask"])
+def test_two_group_step_kernel_is_bit_identical_to_the_one_group_kernel(S, A, B, hidden, variant):
+    """csrc/qnet_fused.hpp: the 512-thread kernel (target net || online net, dZ chain || dW tiles on two wave groups)
+    performs the same arithmetic in the same summation orders as the 256-thread kernel: three learn steps on indexed
+    replay rows give identical parameters, Adam moments, loss statistics and |TD| write-backs."""
+    from porl_amd import _native as NN
+    from porl_amd import engine as E
+    from porl_amd.train.cql_trainer import QnetEngine
+    rng = np.random.default_rng(S * 100 + A)
+    N = 3 * B + 7
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=31)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    st_d, ac_d, rw_d, ns_d, dn_d = dev(st), dev(ac).long(), dev(rw), dev(ns), dev(dn)
+    init = [rng.uniform(-0.3, 0.3, 200_000).astype(np.float32) for _ in range(2)]
+    mask = torch.from_numpy((rng.uniform(size=(B, A)) < 0.6).astype(np.float32)).to(DEV)
+    idxs = [torch.from_numpy(rng.permutation(N)[:B].astype(np.int64)).to(DEV) for _ in range(3)]
+    out = []
+    for two in (1, 0):
+        try:
+            E.tune_set("qnet_two_groups", two)
+            eng = QnetEngine(S, A, hidden, max(B, 64), DEV)
+            assert eng.fused
+            for flat, src in zip((eng.params, eng.params_tgt), init):
+                o = 0
+                for v in eng.views(flat):
+                    v.copy_(torch.from_numpy(src[o:o + v.numel()].reshape(tuple(v.shape))))
+                    o += v.numel()
+            td_abs = torch.zeros(B, device=DEV)
+            var = None
+            if variant == "double_dqn":
+                var = NN.QnetVariant(1, None, None, NN.ptr(td_abs), None, 0)
+            elif variant == "bcq_mask":
+                var = NN.QnetVariant(0, None, None, NN.ptr(td_abs), NN.ptr(mask), 0)
+            for k in range(3):
+                hp = eng.hyper(0.99, 0.7, 1.0 / B, k + 1, 5e-4)
+                eng.learn_indexed(hp, st_d, ac_d, rw_d, ns_d, dn_d, idxs[k], variant=var)
+            torch.cuda.synchronize()
+            out.append([x.clone() for x in (eng.params, eng.adam_m, eng.adam_v, eng.grads, eng.stats[:3], td_abs)])
+        finally:
+            E.tune_set("qnet_two_groups", 1)
+    for a, b, what in zip(out[0], out[1], ("params", "adam_m", "adam_v", "grads", "stats", "td_abs")):
+        assert torch.equal(a, b), what
+
+
 def test_wide_networks_keep_the_multi_launch_path():
     from porl_amd.train.cql_trainer import QnetEngine
     assert not QnetEngine(60, 10, (64, 256, 64), 64, DEV).fused
