@@ -389,6 +389,8 @@ def main():
         if v.strip():
             E.tune_set("tile_map%d" % i, int(v))
             E.tune_set("tile_map_short%d" % i, int(v))
+    if os.environ.get("PORL_VBWD_TILE"):                       # A/B: tile of the value backward in pipelined mode
+        E.tune_set("vbwd_tile_short", int(os.environ["PORL_VBWD_TILE"]))
     if os.environ.get("PORL_L0_TILE"):                         # A/B: tile of the K = 60 forward layers
         E.tune_set("l0_tile", int(os.environ["PORL_L0_TILE"]))
     losses = torch.zeros(a.steps + a.warmup, 8, device=dev)    # device-side loss history, one row per update

@@ -113,6 +113,7 @@ int g_enc_s2d = 0;           // porl_tune_set("enc_s2d", 1): materialise the 2x2
 int g_tile_map[4] = {TILE_64x128, TILE_64x64, TILE_64x128, TILE_64x64};
 int g_tile_map_short[4] = {TILE_64x64, TILE_64x64, TILE_64x128, TILE_64x64};
 thread_local bool g_short_blocks = false;       // set by the IQL entry points from the handle's mode
+int g_vbwd_tile_short = -1;   // porl_tune_set("vbwd_tile_short", t): tile of the value nets' hidden-layer backward in short-block mode (A/B)
 int g_l0_tile = -1;          // porl_tune_set("l0_tile", t): tile override for the K <= 128 forward layers of the IQL step (A/B)
 int g_iql_fold = 1;          // porl_tune_set("iql_fold", 0): porl_iql_step keeps the slab combines as launches of their own (A/B)
 int g_enc_bn_sweep = 0;      // porl_tune_set("enc_bn_sweep", 1): BatchNorm + ReLU of the MLP blocks as a separate sweep (cross-check)
@@ -716,6 +717,7 @@ static int value_backward_impl(porl_iql* h, const porl_iql_hyper* hp, hipStream_
       }
     }
     int tile = pick_tile(g);
+    if (l > 0 && g_short_blocks && g_vbwd_tile_short >= 0) tile = g_vbwd_tile_short;
     if (l == 0) {
       // skinny (H x S) weight gradient: split the batch (K) dimension to fill the chip
       int bm, bn;
@@ -1322,6 +1324,7 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "enc_bn_sweep")) { g_enc_bn_sweep = value != 0; return PORL_OK; }
   if (!strcmp(key, "iql_fold")) { g_iql_fold = value != 0; return PORL_OK; }
   if (!strcmp(key, "l0_tile")) { g_l0_tile = value; return PORL_OK; }
+  if (!strcmp(key, "vbwd_tile_short")) { g_vbwd_tile_short = value; return PORL_OK; }
   if (!strncmp(key, "tile_map_short", 14) && key[14] >= '0' && key[14] <= '3' && !key[15] && value >= 0 && value < TILE_COUNT) {
     g_tile_map_short[key[14] - '0'] = value;
     return PORL_OK;
