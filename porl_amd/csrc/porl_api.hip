@@ -101,6 +101,9 @@ struct ProfScope {
   }
 };
 
+// porl_gemm_f32 diagnostics (scripts/bench_gemm_enc.py): the encoder's operand prologue / epilogue on a bare product
+const float* g_dbg_a_scale = nullptr; const float* g_dbg_a_shift = nullptr; const float* g_dbg_resid = nullptr;
+float* g_dbg_cstat = nullptr;
 unsigned long long* g_qnet_stamps = nullptr;   // porl_tune_set_ptr("qnet_stamps", device buffer of >= 32 u64)
 int g_enc_s2d = 0;           // porl_tune_set("enc_s2d", 1): materialise the 2x2 patches before the merge GEMM (cross-check)
 // What pick_tile returns where its occupancy rule selects tile i (porl_tune_set("tile_map<i>", t) / "tile_map_short<i>").
@@ -1205,6 +1208,11 @@ int porl_gemm_f32(int mode, int tile, int32_t M, int32_t N, int32_t K, const flo
     return PORL_OK;
   }
   g.p[0].bias = bias; g.p[0].act = act; g.p[0].mask = mask; g.p[0].ldmask = ldmask;
+  if (g_dbg_a_scale && g_dbg_a_shift && mode == GEMM_NT) {
+    g.p[0].apro = APRO_AFFINE_RELU; g.p[0].a_colscale = g_dbg_a_scale; g.p[0].a_colshift = g_dbg_a_shift;
+  }
+  if (g_dbg_resid) g.p[0].resid = g_dbg_resid;
+  if (g_dbg_cstat) g.p[0].cstat = g_dbg_cstat;
   return launch_group(g, tile, s);
 }
 
@@ -1339,6 +1347,10 @@ int porl_tune_set(const char* key, int value) {
 int porl_tune_set_ptr(const char* key, void* ptr) {
   if (!key) PORL_FAIL(PORL_ERR_INVALID, "null key");
   if (!strcmp(key, "qnet_stamps")) { g_qnet_stamps = (unsigned long long*)ptr; return PORL_OK; }
+  if (!strcmp(key, "gemm_a_scale")) { g_dbg_a_scale = (const float*)ptr; return PORL_OK; }
+  if (!strcmp(key, "gemm_a_shift")) { g_dbg_a_shift = (const float*)ptr; return PORL_OK; }
+  if (!strcmp(key, "gemm_resid")) { g_dbg_resid = (const float*)ptr; return PORL_OK; }
+  if (!strcmp(key, "gemm_cstat")) { g_dbg_cstat = (float*)ptr; return PORL_OK; }
   PORL_FAIL(PORL_ERR_INVALID, "unknown tuning key '%s'", key);
 }
 
