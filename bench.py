@@ -389,6 +389,13 @@ def main():
         if v.strip():
             E.tune_set("tile_map%d" % i, int(v))
             E.tune_set("tile_map_short%d" % i, int(v))
+    if os.environ.get("PORL_IQL_PAD"):                         # A/B: "value,policy[,min_blocks]" LDS pads of the pipelined update
+        v = [int(x) for x in os.environ["PORL_IQL_PAD"].split(",")]
+        E.tune_set("iql_pad_value", v[0]); E.tune_set("iql_pad_policy", v[1])
+        if len(v) > 2:
+            E.tune_set("iql_pad_min_blocks", v[2])
+    if os.environ.get("PORL_GEMM_LDS_PAD"):                    # A/B: fewer co-resident GEMM blocks per CU (placement knob)
+        E.tune_set("gemm_lds_pad", int(os.environ["PORL_GEMM_LDS_PAD"]))
     if os.environ.get("PORL_VBWD_TILE"):                       # A/B: tile of the value backward in pipelined mode
         E.tune_set("vbwd_tile_short", int(os.environ["PORL_VBWD_TILE"]))
     if os.environ.get("PORL_L0_TILE"):                         # A/B: tile of the K = 60 forward layers

@@ -830,11 +830,12 @@ inline int plan_group(GemmGroup& g, int tile) {
 // Extra dynamic LDS per block (bytes): raises the group-segment size so that fewer blocks fit on a CU.
 // Purely a placement knob (the kernel never touches the extra bytes).
 inline int& gemm_lds_pad() { static int pad = 0; return pad; }
+inline int& gemm_lds_pad_min_blocks() { static int n = 0; return n; }     // launches with fewer blocks are not padded
 
 template <int BM, int BN, int WM, int WN>
 inline hipError_t launch_tile(const GemmGroup& g, hipStream_t s) {
   dim3 grid(g.total_blocks), block(64 * WM * WN);
-  const int pad = gemm_lds_pad();
+  const int pad = g.total_blocks >= gemm_lds_pad_min_blocks() ? gemm_lds_pad() : 0;
   bool vec = true, apro = g.p[0].apro != APRO_NONE;
   for (int i = 0; i < g.nprob; ++i) {
     vec = vec && g.p[i].a_vec && g.p[i].b_vec;

@@ -243,7 +243,29 @@ int pick_splitk(int M, int N, int K, int nprob, int bm, int bn) {
   return std::max(1, std::min(sk, SK_MAX));
 }
 
+// Short-block mode (the pipelined update): how much dynamic LDS a GEMM block of the value ('V') / policy ('P') phase
+// claims on top of its 36 KB of staging buffers, and from how many blocks per launch on.  18 KB -> 55 KB per block ->
+// TWO 64x64 blocks per CU instead of three: a third of every CU's registers (192 of 512 per lane) and 50 KB of LDS stay
+// free, and the other stream's small kernels (56-112 registers per lane: Adam sweep, loss heads, sampler) are placed
+// beside a resident GEMM at once instead of waiting for its blocks to retire.  Measured (bench.py PORL_IQL_PAD=
+// "value,policy,min_blocks", updates/s): none 3 106; every GEMM launch 3 256; value phase only 3 248; policy phase only
+// 3 065; only the launches of >= 1 000 blocks (the value nets' 4 x 1024^3 forward and backward) 3 270; 45 KB (two
+// blocks, no LDS left over) 3 044 — the small kernels need the LDS too.  Default: the value phase's launches of at
+// least 4 blocks per CU (they cannot be resident at once anyway, and they are where the step's time is).
+int g_iql_pad_value = 18432, g_iql_pad_policy = 0, g_iql_pad_min_blocks = 4 * NUM_CU;
+struct PadScope {
+  int saved, saved_min;
+  PadScope() : saved(gemm_lds_pad()), saved_min(gemm_lds_pad_min_blocks()) {
+    if (g_short_blocks && saved == 0) {
+      gemm_lds_pad() = g_phase[0] == 'P' ? g_iql_pad_policy : g_iql_pad_value;
+      gemm_lds_pad_min_blocks() = g_iql_pad_min_blocks;
+    }
+  }
+  ~PadScope() { gemm_lds_pad() = saved; gemm_lds_pad_min_blocks() = saved_min; }
+};
+
 int launch_group(GemmGroup& g, int tile, hipStream_t s) {
+  PadScope _pad;
   double flops = 0.0, bytes = 0.0;
   std::string label;
   if (g_prof.on) {
@@ -1325,6 +1347,10 @@ int porl_per_sample(const double* tree, int64_t capacity, const double* u, int32
 int porl_tune_set(const char* key, int value) {
   if (!key) PORL_FAIL(PORL_ERR_INVALID, "null key");
   if (!strcmp(key, "gemm_lds_pad")) { gemm_lds_pad() = std::max(0, value); return PORL_OK; }
+  if (!strcmp(key, "gemm_lds_pad_min_blocks")) { gemm_lds_pad_min_blocks() = std::max(0, value); return PORL_OK; }
+  if (!strcmp(key, "iql_pad_value")) { g_iql_pad_value = std::max(0, value); return PORL_OK; }
+  if (!strcmp(key, "iql_pad_policy")) { g_iql_pad_policy = std::max(0, value); return PORL_OK; }
+  if (!strcmp(key, "iql_pad_min_blocks")) { g_iql_pad_min_blocks = std::max(0, value); return PORL_OK; }
   if (!strcmp(key, "qnet_fused")) { g_qnet_fused = value != 0; return PORL_OK; }
   if (!strcmp(key, "qnet_two_groups")) { g_qnet_two_groups = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_dense_patch")) { g_enc_dense_patch = value != 0; return PORL_OK; }
