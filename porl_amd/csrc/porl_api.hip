@@ -245,13 +245,14 @@ int pick_splitk(int M, int N, int K, int nprob, int bm, int bn) {
 
 // Short-block mode (the pipelined update): how much dynamic LDS a GEMM block of the value ('V') / policy ('P') phase
 // claims on top of its 36 KB of staging buffers, and from how many blocks per launch on.  18 KB -> 55 KB per block ->
-// TWO 64x64 blocks per CU instead of three: a third of every CU's registers (192 of 512 per lane) and 50 KB of LDS stay
-// free, and the other stream's small kernels (56-112 registers per lane: Adam sweep, loss heads, sampler) are placed
-// beside a resident GEMM at once instead of waiting for its blocks to retire.  Measured (bench.py PORL_IQL_PAD=
-// "value,policy,min_blocks", updates/s): none 3 106; every GEMM launch 3 256; value phase only 3 248; policy phase only
-// 3 065; only the launches of >= 1 000 blocks (the value nets' 4 x 1024^3 forward and backward) 3 270; 45 KB (two
-// blocks, no LDS left over) 3 044 — the small kernels need the LDS too.  Default: the value phase's launches of at
-// least 4 blocks per CU (they cannot be resident at once anyway, and they are where the step's time is).
+// TWO 64x64 blocks per CU instead of three.  Two effects, both measured (bench.py PORL_IQL_PAD="value,policy,min_blocks",
+// PORL_GEMM_LDS_PAD; updates/s): (1) wave quantisation — the value nets' 4 x 1024^3 launches have 1 024 blocks: at three
+// per CU that is one full round of 768 and a ragged one of 256, at two per CU two full rounds (backward launch alone on
+// the chip: 84.6 -> 73.4 us; the 768-block 3-net forward gets WORSE at two per CU, 55.1 -> 59.1 us); (2) room for the
+// other stream — a third of every CU's registers and 50 KB of LDS stay free for the policy stream's small kernels
+// (with a 45 KB pad, i.e. two blocks and NO LDS left over, the update is slower than unpadded: 3 044 vs 3 106).
+// none 3 106; every GEMM launch 3 256; value phase only 3 248; policy phase only 3 065; only launches of >= 1 000 blocks
+// 3 270.  Default: the value phase's launches of at least 4 blocks per CU.
 int g_iql_pad_value = 18432, g_iql_pad_policy = 0, g_iql_pad_min_blocks = 4 * NUM_CU;
 struct PadScope {
   int saved, saved_min;
