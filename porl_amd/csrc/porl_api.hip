@@ -122,6 +122,7 @@ int g_iql_fold = 1;          // porl_tune_set("iql_fold", 0): porl_iql_step keep
 int g_enc_bn_sweep = 0;      // porl_tune_set("enc_bn_sweep", 1): BatchNorm + ReLU of the MLP blocks as a separate sweep (cross-check)
 int g_enc_dense_patch = 0;   // porl_tune_set("enc_dense_patch", 1): rasterise + dense patch embedding (cross-check)
 int g_qnet_fused = 1;     // porl_tune_set("qnet_fused", 0) forces the multi-launch CQL path (A/B measurements)
+int g_qnet_rows16 = 0;      // porl_tune_set("qnet_rows16", 1): 16 rows per block (16x16x4 MFMA tiles) while 32-row blocks leave CUs idle: measured no faster
 int g_qnet_two_groups = 1;  // porl_tune_set("qnet_two_groups", 0): the one-group (256-thread) step kernel (A/B, bit-identical)
 
 constexpr int NUM_CU = 256;
@@ -1354,6 +1355,7 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "iql_pad_min_blocks")) { g_iql_pad_min_blocks = std::max(0, value); return PORL_OK; }
   if (!strcmp(key, "qnet_fused")) { g_qnet_fused = value != 0; return PORL_OK; }
   if (!strcmp(key, "qnet_two_groups")) { g_qnet_two_groups = value != 0; return PORL_OK; }
+  if (!strcmp(key, "qnet_rows16")) { g_qnet_rows16 = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_dense_patch")) { g_enc_dense_patch = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_s2d")) { g_enc_s2d = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_bn_sweep")) { g_enc_bn_sweep = value != 0; return PORL_OK; }
@@ -1455,6 +1457,8 @@ struct porl_qnet {
   QnetFusedArgs fargs{};
   int fused_lds_bytes = 0;
   int fused2_lds_w2 = 0, fused2_lds_bytes = 0;       // two-group kernel: offset of the second weight image; 0 = does not fit
+  QnetFusedArgs fargs16{};                           // the same plan for 16 rows per block (qnet_fused2_kernel<16>)
+  int fused16_lds_w2 = 0, fused16_lds_bytes = 0;
   int64_t fslab_stride = 0;
   bool fslab_clean = false;          // alignment gaps of the flat layout are never written: zeroed once
   bool slab_clean = false;           // same for the split-K slabs of the multi-launch path
@@ -1507,7 +1511,7 @@ int porl_qnet_create(const porl_qnet_cfg* c, porl_qnet** out) {
   h->ws.tmp[0] = take((int64_t)B * maxld); h->ws.tmp[1] = take((int64_t)B * maxld);
   h->ws.dz[0] = take((int64_t)B * maxld); h->ws.dz[1] = take((int64_t)B * maxld);
   h->ws.slab = take((int64_t)SK_MAX * (cur + 64));
-  const int nblk = cdiv(B, QF_ROWS);
+  const int nblk = cdiv(B, 16);                          // (16-row blocks: the finest partition any step kernel uses)
   h->ws.part_td = take(nblk); h->ws.part_pen = take(nblk);
   {
     // LDS plan of the fused kernel
@@ -1535,6 +1539,18 @@ int porl_qnet_create(const porl_qnet_cfg* c, porl_qnet** out) {
         h->fused2_lds_w2 = off;
         h->fused2_lds_bytes = (off + wmax) * (int)sizeof(float);
       }
+    }
+    if (ok && h->fused2_lds_w2 > 0) {
+      // 16-row plan: same buffers, half the rows
+      QnetFusedArgs& f16 = h->fargs16;
+      f16 = fa;
+      int o16 = 0;
+      for (int l = 0; l <= L + 1; ++l) { f16.lds_act[l] = o16; o16 += 16 * (((m.dims[l] + 31) & ~31) + 4); }
+      f16.lds_tmp[0] = o16; o16 += 16 * (maxw + 4);
+      f16.lds_tmp[1] = o16; o16 += 16 * (maxw + 4);
+      f16.lds_w = o16; o16 += wmax;
+      h->fused16_lds_w2 = o16;
+      h->fused16_lds_bytes = (o16 + wmax) * (int)sizeof(float);
     }
     h->fused_ok = ok;
     h->fused_lds_bytes = off * (int)sizeof(float);
@@ -1660,21 +1676,33 @@ static int qnet_fused_backward(porl_qnet* h, const porl_qnet_hyper* hp, int B, c
   if (!attr_set) {
     PORL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  QF_MAX_LDS_BYTES));
-    PORL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_fused2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    PORL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_fused2_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 QF_MAX_LDS_BYTES));
+    PORL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_fused2_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  QF_MAX_LDS_BYTES));
     attr_set = true;
   }
-  const int nblk = cdiv(B, QF_ROWS);
+  // 16 rows per block while 32-row blocks would leave CUs idle (config 3 at B = 4096: 128 blocks on 256 CUs)
+  const bool two = g_qnet_two_groups && h->fused2_lds_w2 > 0;
+  const bool rows16 = two && g_qnet_rows16 && h->fused16_lds_w2 > 0 && cdiv(B, QF_ROWS) < NUM_CU;
+  const int nblk = cdiv(B, rows16 ? 16 : QF_ROWS);
+  if (rows16) {
+    const QnetFusedArgs& f16 = h->fargs16;
+    for (int l = 0; l <= QF_MAX_LIN; ++l) a.lds_act[l] = f16.lds_act[l];
+    a.lds_tmp[0] = f16.lds_tmp[0]; a.lds_tmp[1] = f16.lds_tmp[1]; a.lds_w = f16.lds_w;
+  }
   if (!h->fslab_clean) {
-    PORL_HIP(hipMemsetAsync(W + h->ws.fslab, 0, sizeof(float) * cdiv(h->cfg.max_batch, QF_ROWS) * h->fslab_stride, s));
+    PORL_HIP(hipMemsetAsync(W + h->ws.fslab, 0, sizeof(float) * cdiv(h->cfg.max_batch, 16) * h->fslab_stride, s));
     h->fslab_clean = true;
   }
   {
     double macs = 0;
     for (int l = 0; l < a.n_lin; ++l) macs += (double)a.dims[l] * a.dims[l + 1];
     ProfScope ps("qnet_fused_kernel", s, 2.0 * B * macs * 4.0, 8.0 * B * a.dims[0]);
-    if (g_qnet_two_groups && h->fused2_lds_w2 > 0)
-      hipLaunchKernelGGL(qnet_fused2_kernel, dim3(nblk), dim3(512), (size_t)h->fused2_lds_bytes, s, a, h->fused2_lds_w2);
+    if (rows16)
+      hipLaunchKernelGGL(qnet_fused2_kernel<16>, dim3(nblk), dim3(512), (size_t)h->fused16_lds_bytes, s, a, h->fused16_lds_w2);
+    else if (two)
+      hipLaunchKernelGGL(qnet_fused2_kernel<32>, dim3(nblk), dim3(512), (size_t)h->fused2_lds_bytes, s, a, h->fused2_lds_w2);
     else
       hipLaunchKernelGGL(qnet_fused_kernel, dim3(nblk), dim3(256), (size_t)h->fused_lds_bytes, s, a);
     PORL_HIP(hipGetLastError());

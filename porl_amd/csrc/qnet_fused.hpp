@@ -286,11 +286,11 @@ __device__ __forceinline__ void qf_loss_row_regs(const QnetFusedArgs& a, const f
 // the Q buffer itself: a lane reads q[j] before it writes dq[j].  Leaves the block's partial sums in red[0..1].
 __device__ __forceinline__ void qf_loss_rows(const QnetFusedArgs& a, const float* Q, const float* Qn, float* dz, const int* amax,
                                              int row_act, float row_rew, float row_done, int row0, int lane, int wave,
-                                             float* red) {
+                                             float* red, int rows = QF_ROWS) {
   const int A = a.dims[a.n_lin], ldq = qf_r32(A) + 4;
   if (wave == 0) {
     float td = 0.f, pen = 0.f;
-    if (lane < QF_ROWS) {
+    if (lane < rows) {
       const int b = row0 + lane;
       float* dq = dz + lane * ldq;
       if (b < a.B && A <= 32) {
@@ -569,8 +569,8 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
 // branch per slot — `if (u * 256 < total)`, `idx ? idx[b] : b` — the compiler closed every slot with s_waitcnt
 // vmcnt(0): nine dependent round trips to HBM at kernel entry instead of two, ~12 k cycles.)
 struct QfInput { long row[QF_XREGS]; float v[QF_XREGS]; };
-__device__ __forceinline__ void qf_input_rows(QfInput& in, int ld, const int64_t* idx, int row0, int B, int t) {
-  const int total = QF_ROWS * ld;
+__device__ __forceinline__ void qf_input_rows(QfInput& in, int ld, const int64_t* idx, int row0, int B, int t, int rows = QF_ROWS) {
+  const int total = rows * ld;
   const float inv_ld = 1.0f / (float)ld;
   if (idx) {
 #pragma unroll
@@ -587,8 +587,9 @@ __device__ __forceinline__ void qf_input_rows(QfInput& in, int ld, const int64_t
     }
   }
 }
-__device__ __forceinline__ void qf_input_load(QfInput& in, int ld, const float* src, long rs, int row0, int B, int cols, int t) {
-  const int total = QF_ROWS * ld;
+__device__ __forceinline__ void qf_input_load(QfInput& in, int ld, const float* src, long rs, int row0, int B, int cols, int t,
+                                              int rows = QF_ROWS) {
+  const int total = rows * ld;
   const float inv_ld = 1.0f / (float)ld;
 #pragma unroll
   for (int u = 0; u < QF_XREGS; ++u) {
@@ -599,8 +600,8 @@ __device__ __forceinline__ void qf_input_load(QfInput& in, int ld, const float* 
     in.v[u] = ok ? x : 0.f;
   }
 }
-__device__ __forceinline__ void qf_input_store(const QfInput& in, float* dst, int ld, int t) {
-  const int total = QF_ROWS * ld;
+__device__ __forceinline__ void qf_input_store(const QfInput& in, float* dst, int ld, int t, int rows = QF_ROWS) {
+  const int total = rows * ld;
 #pragma unroll
   for (int u = 0; u < QF_XREGS; ++u) {
     const int i = u * 256 + t;
@@ -608,6 +609,149 @@ __device__ __forceinline__ void qf_input_store(const QfInput& in, float* dst, in
   }
 }
 
+// ---- 16 minibatch rows per block on v_mfma_f32_16x16x4_f32 (opt-in: porl_tune_set("qnet_rows16", 1)) ---------------
+// Config 3 at B = 4096 is 128 blocks of 32 rows: half of the chip idles, and inside a block the stage time is the
+// dependent chain of 64-cycle 32x32x2 MFMAs of one or two column slabs.  With 16 rows per block the same batch is 256
+// blocks, and a layer is 16 x 16 tiles (32-cycle MFMAs over 4 reduction indices): a 64-wide layer is four tiles = one
+// per wave, its chain K/4 x 32 cycles — a quarter of the 32-row kernel's.  MEASURED: no faster (43.2 vs 42.4 us; the
+// dZ chain 9.6 k -> 3.9 k cycles per layer, but a forward tile of 16 MFMAs takes 2.3-3.7 k cycles where the bare
+// instruction stream (scripts/mfma_rate.hip: 32.2 cycles per MFMA, 86 with LDS operands at two waves per SIMD) needs
+// 1.4 k, and the 256 partial-gradient slabs cost the reduce launch +1.8 us) — so 32 rows stay the default.  The stage
+// time of these kernels is not the matrix pipe's.  Lane l = (l16 = l & 15, kq = l >> 4) supplies
+// A[row l16][k] and B[k][col l16] for k = 4 kq + j in MFMA j of a batch of 16 reduction indices (any k order is legal as
+// long as A and B agree), so each operand is ONE 16-byte read per batch; D register i is row 4 kq + i, column l16.
+typedef float qf_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NB>
+__device__ __forceinline__ void qf16_kk_batches(const float* ap, const float* bp, qf_f32x4& acc, qf_f32x4& acc1) {
+  float4 av[NB], bv[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    av[b] = *reinterpret_cast<const float4*>(ap + 16 * b);
+    bv[b] = *reinterpret_cast<const float4*>(bp + 16 * b);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b].x, bv[b].x, acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b].y, bv[b].y, acc1, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b].z, bv[b].z, acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b].w, bv[b].w, acc1, 0, 0, 0);
+  }
+}
+
+// out[16][ldo] = act(in[16][ldi] . Wl^T + bias): 16-column tiles w, w+4, ... per wave (all round32(N) columns are
+// written: the zero rows of the weight image give the zero padding the next layer's reduction reads)
+__device__ __forceinline__ void qf16_forward(const float* in, int ldi, const float* wl, int K, int N, const float* bias, bool relu,
+                                             float* out, int ldo, int wave, int l16, int kq) {
+  const int ldw = qf_rk(K) + 4, nb = qf_rk(K) >> 4;
+  for (int tn = wave; tn < qf_r32(N) / 16; tn += 4) {
+    qf_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = in + l16 * ldi + 4 * kq;
+    const float* bp = wl + (tn * 16 + l16) * ldw + 4 * kq;
+    switch (nb) {
+      case 1: qf16_kk_batches<1>(ap, bp, acc, acc1); break;
+      case 2: qf16_kk_batches<2>(ap, bp, acc, acc1); break;
+      case 3: qf16_kk_batches<3>(ap, bp, acc, acc1); break;
+      case 4: qf16_kk_batches<4>(ap, bp, acc, acc1); break;
+      case 5: qf16_kk_batches<5>(ap, bp, acc, acc1); break;
+      case 6: qf16_kk_batches<6>(ap, bp, acc, acc1); break;
+      case 7: qf16_kk_batches<7>(ap, bp, acc, acc1); break;
+      default: qf16_kk_batches<8>(ap, bp, acc, acc1); break;
+    }
+    const int col = tn * 16 + l16;
+    const float bv = bias[col];                    // zero past N
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = acc[i] + acc1[i] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      if (col >= N) v = 0.f;
+      out[(4 * kq + i) * ldo + col] = v;
+    }
+  }
+}
+
+// dZ_{l-1} = (dZ . W_l) * 1[in > 0] for 16 rows: 16-column tiles of K over the waves, reduction over n in batches of 16
+// (lane quarter kq takes n0 + 4 kq + j: one 16-byte read of its dZ row, four 4-byte reads of consecutive weight columns)
+template <int NB>
+__device__ __forceinline__ void qf16_nn_batches(const float* ap, const float* bp, int ldw, qf_f32x4& acc, qf_f32x4& acc1) {
+  float4 av[NB];
+  float bv[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    av[b] = *reinterpret_cast<const float4*>(ap + 16 * b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[b][j] = bp[(16 * b + j) * ldw];
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b].x, bv[b][0], acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b].y, bv[b][1], acc1, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b].z, bv[b][2], acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b].w, bv[b][3], acc1, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void qf16_dgrad(const float* dz, int lddz, const float* wl, int N, int K, const float* in, int ldin,
+                                           float* dzp, int wave, int l16, int kq) {
+  const int ldw = qf_rk(K) + 4, Np = qf_r32(N);
+  for (int tk = wave; tk < qf_r32(K) / 16; tk += 4) {
+    qf_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = dz + l16 * lddz + 4 * kq;
+    const float* bp = wl + 4 * kq * ldw + tk * 16 + l16;
+    for (int n0 = 0; n0 < Np; n0 += 64) {          // Np is a multiple of 32
+      if (Np - n0 >= 64) qf16_nn_batches<4>(ap + n0, bp + n0 * ldw, ldw, acc, acc1);
+      else qf16_nn_batches<2>(ap + n0, bp + n0 * ldw, ldw, acc, acc1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int col = tk * 16 + l16;
+    float act[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) act[i] = in[(4 * kq + i) * ldin + col];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dzp[(4 * kq + i) * ldin + col] = (col < K && act[i] > 0.f) ? acc[i] + acc1[i] : 0.f;
+  }
+}
+
+// dW_l = dZ^T . in over the block's 16 rows: 16 x 16 tiles of (n, k), four MFMAs each, dealt over `nw` waves; db_l = column
+// sums of dZ over `nt` threads.  Tiles that lie entirely in the padding are skipped.
+__device__ __forceinline__ void qf16_wgrad(const QnetFusedArgs& a, int l, const float* dz, const float* in, float* slab, int w,
+                                           int nw, int l16, int kq, int t, int nt) {
+  const int N = a.dims[l + 1], K = a.dims[l];
+  const int lddz = qf_r32(N) + 4, ldin = qf_r32(K) + 4;
+  const int tiles_n = (N + 15) / 16, tiles_k = (K + 15) / 16;
+  float* const wslab = slab + a.w_off[l];
+  float* const bslab = slab + a.b_off[l];
+  const int ldp = qf_rk(K) + 4;
+  for (int tile = w; tile < tiles_n * tiles_k; tile += nw) {
+    const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+    float av[4], bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      av[j] = dz[(4 * j + kq) * lddz + tn * 16 + l16];
+      bv[j] = in[(4 * j + kq) * ldin + tk * 16 + l16];
+    }
+    qf_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc1, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc1, 0, 0, 0);
+    const int k = tk * 16 + l16;
+    float* const wp = wslab + (tn * 16 + 4 * kq) * ldp + k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (tn * 16 + 4 * kq + i < N && k < K) wp[i * ldp] = acc[i] + acc1[i];
+  }
+  for (int n = t; n < N; n += nt) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = dz[r * lddz + n];
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += v[r];
+    bslab[n] = s;
+  }
+}
+
+template <int ROWS>
 __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a, int lds_w2) {
   extern __shared__ float qf_lds[];
   __shared__ float red[2];
@@ -617,7 +761,8 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
   // a SIMD.  Layers with fewer than four 32-column slabs occupy waves 0.. only, so group 1 numbers its waves from 2:
   // the busy waves of the two groups then sit on different SIMDs.
   const int wave = (((t >> 6) & 3) + 2 * grp) & 3;
-  const int row0 = blockIdx.x * QF_ROWS;
+  const int l16 = lane & 15, kq = lane >> 4;          // lane coordinates of the 16 x 16 x 4 tiles (ROWS == 16)
+  const int row0 = blockIdx.x * ROWS;
   const int L = a.n_lin - 1;
   float* const wbuf0 = qf_lds + a.lds_w;
   float* const wbuf1 = qf_lds + lds_w2;
@@ -673,14 +818,14 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
   // image and the loss stage's per-row scalars (lanes 0..31 of wave 0; see the one-group kernel) while they are in flight.
   // Group 0 gathers s' (for the target net), group 1 gathers s.
   QfInput xin;
-  qf_input_rows(xin, ldx, a.idx, row0, a.B, tg);
-  const int my_row = row0 + (t < QF_ROWS ? t : 0);
+  qf_input_rows(xin, ldx, a.idx, row0, a.B, tg, ROWS);
+  const int my_row = row0 + (t < ROWS ? t : 0);
   const long my_src = my_row < a.B ? (a.idx ? a.idx[my_row] : (long)my_row) : 0L;
   dma(0, wl);
-  qf_input_load(xin, ldx, grp ? a.states : a.next_states, grp ? a.s_rs : a.n_rs, row0, a.B, a.dims[0], tg);
+  qf_input_load(xin, ldx, grp ? a.states : a.next_states, grp ? a.s_rs : a.n_rs, row0, a.B, a.dims[0], tg, ROWS);
   const int row_act = (int)a.actions[my_src];
   const float row_rew = a.rew[my_src], row_done = a.done[my_src];
-  qf_input_store(xin, grp ? X : Xn, ldx, tg);
+  qf_input_store(xin, grp ? X : Xn, ldx, tg, ROWS);
   stamp();
 
   // ---- forward: role 1 = target net on s' (ping-pong in tmp), 2 = online net on s' (Double DQN: argmax kept),
@@ -698,13 +843,16 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
         const float* in = l == 0 ? (role == 3 ? X : Xn) : (role == 1 ? qf_lds + a.lds_tmp[(l - 1) & 1] : qf_lds + a.lds_act[l]);
         float* out = role == 1 ? qf_lds + a.lds_tmp[l & 1] : qf_lds + a.lds_act[l + 1];
         const float* bl = wl + qf_r32(a.dims[l + 1]) * (qf_rk(a.dims[l]) + 4);
-        qf_forward(in, qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L, out, qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
+        if constexpr (ROWS == 16)
+          qf16_forward(in, qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L, out, qf_r32(a.dims[l + 1]) + 4, wave, l16, kq);
+        else
+          qf_forward(in, qf_r32(a.dims[l]) + 4, wl, a.dims[l], a.dims[l + 1], bl, l < L, out, qf_r32(a.dims[l + 1]) + 4, wave, li, kh);
         stamp();
       }
       qf_barrier();
       stamp();
     }
-    if (role == 2 && tg < QF_ROWS) {
+    if (role == 2 && tg < ROWS) {
       const float* q = qf_lds + a.lds_act[L + 1] + tg * (qf_r32(a.dims[L + 1]) + 4);
       int best = 0;
       for (int j = 1; j < a.dims[L + 1]; ++j) best = q[j] > q[best] ? j : best;     // first maximum, like torch.max
@@ -720,7 +868,7 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
   // forward barrier, so group 0's forward buffer is dead — and lands while the loss is computed.
   auto bsel = [&](int l) __attribute__((always_inline)) { return ((L - l) & 1) ? wbuf0 : wbuf1; };
   if (grp == 0 && L > 1) dma(L + 2, bsel(L - 1));
-  if (grp == 0) qf_loss_rows(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, row_act, row_rew, row_done, row0, lane, wave, red);
+  if (grp == 0) qf_loss_rows(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, row_act, row_rew, row_done, row0, lane, wave, red, ROWS);
   if (grp == 0) barrier_vm(); else qf_barrier();
   if (t == 0) { a.part_td[blockIdx.x] = red[0]; a.part_pen[blockIdx.x] = red[1]; }
   stamp();
@@ -739,12 +887,14 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
     if (grp == 0) {
       if (l < L && l > 1) dma(2 * L + 2 - l, bsel(l - 1));            // W_{l-1} into the buffer dgrad(l + 1) is done with
       stamp();
-      qf_dgrad(dz, lddz, bsel(l), N, K, in, ldin, dzp, wave, li, kh);
+      if constexpr (ROWS == 16) qf16_dgrad(dz, lddz, bsel(l), N, K, in, ldin, dzp, wave, l16, kq);
+      else qf_dgrad(dz, lddz, bsel(l), N, K, in, ldin, dzp, wave, li, kh);
       stamp();
       barrier_vm();
     } else {
       stamp2();
-      qf_wgrad_n(a, l, dz, in, slab, wave, 4, li, kh, tg, 256);
+      if constexpr (ROWS == 16) qf16_wgrad(a, l, dz, in, slab, wave, 4, l16, kq, tg, 256);
+      else qf_wgrad_n(a, l, dz, in, slab, wave, 4, li, kh, tg, 256);
       stamp2();
       qf_barrier();
     }
@@ -752,7 +902,8 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
     stamp();
   }
   // layer 0 has no dZ to pass on: all eight waves share its dW tiles
-  qf_wgrad_n(a, 0, dz, qf_lds + a.lds_act[0], slab, (t >> 6), 8, li, kh, t, 512);
+  if constexpr (ROWS == 16) qf16_wgrad(a, 0, dz, qf_lds + a.lds_act[0], slab, (t >> 6), 8, l16, kq, t, 512);
+  else qf_wgrad_n(a, 0, dz, qf_lds + a.lds_act[0], slab, (t >> 6), 8, li, kh, t, 512);
   stamp();
 }
 

@@ -181,7 +181,8 @@ def test_one_launch_gradients_on_odd_shapes(S, A, B, hidden):
 def test_two_group_step_kernel_is_bit_identical_to_the_one_group_kernel(S, A, B, hidden, variant):
     """csrc/qnet_fused.hpp: the 512-thread kernel (target net || online net, dZ chain || dW tiles on two wave groups)
     performs the same arithmetic in the same summation orders as the 256-thread kernel: three learn steps on indexed
-    replay rows give identical parameters, Adam moments, loss statistics and |TD| write-backs."""
+    replay rows give identical parameters, Adam moments, loss statistics and |TD| write-backs.  Its 16-row form
+    (v_mfma_f32_16x16x4_f32, twice as many blocks, other partial-sum grouping) agrees to rounding."""
     from porl_amd import _native as NN
     from porl_amd import engine as E
     from porl_amd.train.cql_trainer import QnetEngine
@@ -194,9 +195,10 @@ def test_two_group_step_kernel_is_bit_identical_to_the_one_group_kernel(S, A, B,
     mask = torch.from_numpy((rng.uniform(size=(B, A)) < 0.6).astype(np.float32)).to(DEV)
     idxs = [torch.from_numpy(rng.permutation(N)[:B].astype(np.int64)).to(DEV) for _ in range(3)]
     out = []
-    for two in (1, 0):
+    for two, rows16 in ((1, 0), (0, 0), (1, 1)):
         try:
             E.tune_set("qnet_two_groups", two)
+            E.tune_set("qnet_rows16", rows16)
             eng = QnetEngine(S, A, hidden, max(B, 64), DEV)
             assert eng.fused
             for flat, src in zip((eng.params, eng.params_tgt), init):
@@ -217,8 +219,13 @@ def test_two_group_step_kernel_is_bit_identical_to_the_one_group_kernel(S, A, B,
             out.append([x.clone() for x in (eng.params, eng.adam_m, eng.adam_v, eng.grads, eng.stats[:3], td_abs)])
         finally:
             E.tune_set("qnet_two_groups", 1)
-    for a, b, what in zip(out[0], out[1], ("params", "adam_m", "adam_v", "grads", "stats", "td_abs")):
+            E.tune_set("qnet_rows16", 0)
+    names = ("params", "adam_m", "adam_v", "grads", "stats", "td_abs")
+    for a, b, what in zip(out[0], out[1], names):
         assert torch.equal(a, b), what
+    for a, c, what in zip(out[0], out[2], names):
+        scale = max(float(a.abs().max()), 1e-3)
+        assert float((a - c).abs().max()) <= 3e-6 * max(scale, 1.0) + 2e-6 * scale, what
 
 
 def test_wide_networks_keep_the_multi_launch_path():
