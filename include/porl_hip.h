@@ -425,6 +425,14 @@ int porl_tune_set(const char* key, int value);
  * the phase boundaries of the one-launch CQL kernel (NULL switches it off). */
 int porl_tune_set_ptr(const char* key, void* ptr);
 
+/* Stream signals (no reference counterpart; used by the pipelined update of porl_amd/agent/_iql.py): a 64-bit counter
+ * in device signal memory.  porl_signal_write enqueues "counter = value" on `stream` (after everything enqueued before
+ * it), porl_signal_wait_ge holds `stream` until counter >= value.  Values must only grow. */
+int porl_signal_create(void** out);
+int porl_signal_destroy(void* sig);
+int porl_signal_write(void* sig, uint64_t value, void* stream);
+int porl_signal_wait_ge(void* sig, uint64_t value, void* stream);
+
 /* Per-launch timing with HIP events on the launch stream (off by default; adds two event records per
  * kernel).  porl_prof_read synchronises the device and returns the number of entries filled. */
 typedef struct porl_prof_entry {

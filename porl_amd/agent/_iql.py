@@ -13,6 +13,11 @@ from ..engine import IqlEngine
 from ..parallel import GradExchange
 
 
+
+# cross-stream ordering of the pipelined update: "signal" = counters in signal memory (engine.py: 3 380 vs 3 300 updates/s),
+# "event" = event record / stream-wait-event pairs (A/B, and the fallback where wait-value operations are missing)
+_PIPE_SYNC = __import__("os").environ.get("PORL_PIPE_SYNC", "signal")
+
 class ArenaAdam:
     """torch.optim.Adam look-alike over one flat parameter group of the engine.
 
@@ -202,7 +207,14 @@ class IqlAgentBase(nn.Module):
         eng._ensure_bound()
         eng.set_mode(((IqlEngine.MODE_TWO_SLOTS | IqlEngine.MODE_SHORT_BLOCKS) if pipelined else 0) |
                      (IqlEngine.MODE_FOLD_COMBINE if world == 1 else 0))
-        if pipelined:
+        use_sig = pipelined and _PIPE_SYNC == "signal" and eng.signals() is not None
+        if use_sig:
+            main = torch.cuda.current_stream(eng.device)
+            eng._seq += 1
+            seq = eng._seq
+            # the policy phase SLOTS updates ago used the staging slot loaded next
+            eng.wait_signal(eng.SIG_POLICY, seq - eng.SLOTS, main)
+        elif pipelined:
             eng.wait_slot_free()               # the policy phase SLOTS updates ago used the staging slot loaded next
         if replay is not None:
             B = eng.load_batch_sampled(replay.rows, batch, replay.seed, replay.draws, replay.act_dim,
@@ -225,18 +237,30 @@ class IqlAgentBase(nn.Module):
         else:
             if world > 1:
                 ex.allreduce_sum_(eng.grads_vf)
-            eng.wait_values_read()             # the PREVIOUS update's policy phase has read the old value nets
+            if use_sig:
+                eng.wait_signal(eng.SIG_FWD, seq - 1, main)
+            else:
+                eng.wait_values_read()         # the PREVIOUS update's policy phase has read the old value nets
             eng.value_apply(hp)
         # ---- policy phase -------------------------------------------------------------------------------------------
         if pipelined:
             main, side = torch.cuda.current_stream(eng.device), eng.side_stream()
             k = (v_opt.step_count % eng.SLOTS) * 3
             ev_v, ev_f, ev_p = eng.event(k), eng.event(k + 1), eng.event(k + 2)
-            ev_v.record(main)
+            if use_sig:
+                eng.signal(eng.SIG_VALUE, seq, main)
+            else:
+                ev_v.record(main)
             with torch.cuda.stream(side):
-                side.wait_event(ev_v)
+                if use_sig:
+                    eng.wait_signal(eng.SIG_VALUE, seq, side)
+                else:
+                    side.wait_event(ev_v)
                 eng.policy_forward(hp)                    # every read of the value nets the policy phase makes
-                ev_f.record(side)
+                if use_sig:
+                    eng.signal(eng.SIG_FWD, seq, side)
+                else:
+                    ev_f.record(side)
                 eng.policy_backward(hp)
                 if world > 1 and self._sharded():         # loss statistics stay per-rank shares in this mode
                     self._sharded_apply(IqlEngine.GROUP_POL, hp, p_opt)
@@ -244,10 +268,13 @@ class IqlAgentBase(nn.Module):
                     if world > 1:
                         ex.allreduce_sum_(eng.grads_pol)
                     eng.policy_apply(hp)
-                ev_p.record(side)
+                if use_sig:
+                    eng.signal(eng.SIG_POLICY, seq, side)     # (join() records its own event on the side stream)
+                else:
+                    ev_p.record(side)
             # the next value Adam waits for ev_f only; readers of the agent (flush) wait for ev_p
-            eng._values_read, eng._policy_done = ev_f, ev_p
-            eng._slot_users = eng._slot_users[1:] + [ev_p]
+            eng._values_read, eng._policy_done = (None if use_sig else ev_f), (True if use_sig else ev_p)
+            eng._slot_users = eng._slot_users[1:] + [None if use_sig else ev_p]
         else:
             eng.policy_backward(hp)
             if self._sharded():

@@ -1373,6 +1373,38 @@ int porl_tune_set(const char* key, int value) {
   PORL_FAIL(PORL_ERR_INVALID, "unknown tuning key '%s'", key);
 }
 
+// ---- stream signals: cross-stream ordering by 64-bit counters in signal memory ----------------------------------------
+// (hipStreamWriteValue64 / hipStreamWaitValue64 on memory from hipExtMallocWithFlags(hipMallocSignalMemory): the command
+// processor writes / polls a value in stream order.)  The pipelined update orders its two streams three times per
+// update; as event record + stream-wait-event pairs each crossing showed up as 6-12 us of idle queue in the kernel
+// trace even when the event had completed long before.
+int porl_signal_create(void** out) {
+  if (!out) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  int dev = 0, can = 0;
+  PORL_HIP(hipGetDevice(&dev));
+  PORL_HIP(hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev));
+  if (!can) PORL_FAIL(PORL_ERR_UNSUPPORTED, "stream wait-value operations are not supported on this device");
+  void* p = nullptr;
+  PORL_HIP(hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory));
+  PORL_HIP(hipMemset(p, 0, 8));
+  *out = p;
+  return PORL_OK;
+}
+int porl_signal_destroy(void* sig) {
+  if (sig) PORL_HIP(hipFree(sig));
+  return PORL_OK;
+}
+int porl_signal_write(void* sig, uint64_t value, void* stream) {
+  if (!sig) PORL_FAIL(PORL_ERR_INVALID, "null signal");
+  PORL_HIP(hipStreamWriteValue64((hipStream_t)stream, sig, value, 0));
+  return PORL_OK;
+}
+int porl_signal_wait_ge(void* sig, uint64_t value, void* stream) {
+  if (!sig) PORL_FAIL(PORL_ERR_INVALID, "null signal");
+  PORL_HIP(hipStreamWaitValue64((hipStream_t)stream, sig, value, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+  return PORL_OK;
+}
+
 int porl_tune_set_ptr(const char* key, void* ptr) {
   if (!key) PORL_FAIL(PORL_ERR_INVALID, "null key");
   if (!strcmp(key, "qnet_stamps")) { g_qnet_stamps = (unsigned long long*)ptr; return PORL_OK; }

@@ -63,10 +63,41 @@ class IqlEngine:
             self._events.append(torch.cuda.Event(enable_timing=False, blocking=False))
         return self._events[i]
 
+    # Cross-stream ordering of the pipelined update by counters in signal memory (csrc: porl_signal_*).  Three counters:
+    # 0 = value Adam done (update number), 1 = policy forward half done, 2 = policy phase done.  PORL_PIPE_SYNC=event
+    # keeps the event record / stream-wait-event pairs (A/B).
+    SIG_VALUE, SIG_FWD, SIG_POLICY = 0, 1, 2
+
+    def signals(self):
+        """The three counters, or None when the device has no stream wait-value operations (events are used then)."""
+        if getattr(self, "_signals", None) is None:
+            sig = []
+            with torch.cuda.device(self.device):
+                for _ in range(3):
+                    p = C.c_void_p()
+                    if self._lib.porl_signal_create(C.byref(p)) != 0:
+                        sig = False
+                        break
+                    sig.append(p)
+            self._signals = sig
+            self._seq = 0
+        return self._signals or None
+
+    def signal(self, which, value, stream):
+        N.check(self._lib.porl_signal_write(self.signals()[which], int(value), C.c_void_p(stream.cuda_stream)), "porl_signal_write")
+
+    def wait_signal(self, which, value, stream):
+        if value > 0:
+            N.check(self._lib.porl_signal_wait_ge(self.signals()[which], int(value), C.c_void_p(stream.cuda_stream)),
+                    "porl_signal_wait_ge")
+
     def join(self):
         """Order the current stream behind an outstanding policy phase on the side stream (no host wait)."""
         ev, self._policy_done, self._values_read = self._policy_done, None, None
         self._slot_users = [None] * self.SLOTS
+        if ev is True:                                 # signal mode: no per-update event; order behind the side stream now
+            ev = self.event(3 * self.SLOTS)
+            ev.record(self.side_stream())
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
 
@@ -128,6 +159,8 @@ class IqlEngine:
         if device == self.device:
             return self
         self.join()
+        torch.cuda.synchronize(self.device)
+        self._free_signals()
         self._side, self._events = None, []
         for name in ("params_vf", "params_tgt", "params_pol", "grads_vf", "grads_pol", "adam_m_vf",
                      "adam_v_vf", "adam_m_pol", "adam_v_pol", "stats"):
@@ -258,8 +291,14 @@ class IqlEngine:
                                                   N.current_stream_ptr(self.device)), "porl_iql_forward_policy")
         return mean
 
+    def _free_signals(self):
+        for p in (getattr(self, "_signals", None) or []):
+            self._lib.porl_signal_destroy(p)
+        self._signals = None
+
     def __del__(self):
         try:
+            self._free_signals()
             if getattr(self, "_h", None):
                 self._lib.porl_iql_destroy(self._h)
                 self._h = None
