@@ -207,13 +207,18 @@ class IqlAgentBase(nn.Module):
         eng._ensure_bound()
         eng.set_mode(((IqlEngine.MODE_TWO_SLOTS | IqlEngine.MODE_SHORT_BLOCKS) if pipelined else 0) |
                      (IqlEngine.MODE_FOLD_COMBINE if world == 1 else 0))
-        use_sig = pipelined and _PIPE_SYNC == "signal" and eng.signals() is not None
+        use_sig = pipelined and _PIPE_SYNC in ("signal", "signal2") and eng.signals() is not None
         if use_sig:
             main = torch.cuda.current_stream(eng.device)
             eng._seq += 1
             seq = eng._seq
-            # the policy phase SLOTS updates ago used the staging slot loaded next
-            eng.wait_signal(eng.SIG_POLICY, seq - eng.SLOTS, main)
+            # The staging slot loaded next was last read by the policy phase SLOTS = 3 updates ago.  Strictly no wait is
+            # needed for it: this stream has already waited (before its previous value Adam) for the forward half of policy
+            # phase seq - 2, which the in-order side stream only starts after policy phase seq - 3 has finished.  The wait
+            # (and the counter write it pairs with) is kept because it measures FASTER than leaving it out — 3 372 vs
+            # 3 348 updates/s, three runs each on one device (PORL_PIPE_SYNC=signal2 is the variant without).
+            if _PIPE_SYNC == "signal":
+                eng.wait_signal(eng.SIG_POLICY, seq - eng.SLOTS, main)
         elif pipelined:
             eng.wait_slot_free()               # the policy phase SLOTS updates ago used the staging slot loaded next
         if replay is not None:
@@ -268,9 +273,9 @@ class IqlAgentBase(nn.Module):
                     if world > 1:
                         ex.allreduce_sum_(eng.grads_pol)
                     eng.policy_apply(hp)
-                if use_sig:
-                    eng.signal(eng.SIG_POLICY, seq, side)     # (join() records its own event on the side stream)
-                else:
+                if _PIPE_SYNC == "signal" and use_sig:
+                    eng.signal(eng.SIG_POLICY, seq, side)
+                if not use_sig:                               # (signal mode: join() records its own event when needed)
                     ev_p.record(side)
             # the next value Adam waits for ev_f only; readers of the agent (flush) wait for ev_p
             eng._values_read, eng._policy_done = (None if use_sig else ev_f), (True if use_sig else ev_p)
