@@ -76,6 +76,24 @@ class GaussianPolicy(_EngineBacked):
         dist = self(obs)
         return dist.mean if deterministic else dist.sample()
 
+    def mean_numpy(self, obs):
+        """The distribution's mean as a numpy array — what `select_action` returns (reference sorl.py:71-76).  Up to
+        8 observations take the host-memory fast path of the engine (three launches, no copies); larger batches the
+        ordinary forward."""
+        squeeze = obs.ndim == 1
+        if squeeze:
+            obs = obs[None]
+        B = int(obs.shape[0])
+        if self._engine is None or (self._private and self._engine.cfg.max_batch < B):
+            self._attach_private(B)
+        if B <= self._engine.SMALL_BATCH:
+            out = self._engine.forward_policy_host(obs)
+        else:
+            if not isinstance(obs, torch.Tensor):
+                obs = torch.as_tensor(obs, dtype=torch.float32)
+            out = self._engine.forward_policy(obs.to(self._engine.device)).cpu().numpy()
+        return out[0] if squeeze else out
+
 
 class BoundedGaussianPolicy(GaussianPolicy):
     """Tanh-squashed mean (reference policy.py:35-59).  The reference's |mean|>1 pdb trap is unreachable

@@ -55,7 +55,7 @@ class SORL(IqlAgentBase):
         agent.flush()
         if agent.backbone is not None:
             observations = agent.backbone(observations)
-        return agent.policy(observations).mean.cpu().numpy()
+        return agent.policy.mean_numpy(observations)
 
     def update(agent, observations, actions, rewards, next_observations, terminals):
         """Joint value + policy step (reference sorl.py:78-128) -> (v_loss, g_loss).  With a backbone both

@@ -291,6 +291,36 @@ class IqlEngine:
                                                   N.current_stream_ptr(self.device)), "porl_iql_forward_policy")
         return mean
 
+    SMALL_BATCH = 8                                       # kernels.hpp: SMALL_FWD_MAX_B
+
+    def forward_policy_host(self, x):
+        """Rollout path (reference test.py:28-30: one observation in, one action out as numpy): the three small-batch
+        launches read the observation from and write the mean to PINNED HOST memory — no copy launches, no torch
+        kernels, one stream synchronisation.  `x`: (B <= 8, obs_dim) float32, a device tensor, a CPU tensor or an
+        ndarray.  Returns a fresh (B, D) float32 ndarray."""
+        self._ensure_bound()
+        self.join()
+        B, D, S = int(x.shape[0]), self.cfg.pol_out_dim, self.cfg.obs_dim
+        if B < 1 or B > self.SMALL_BATCH or tuple(x.shape) != (B, S):
+            raise RuntimeError(f"obs: expected shape (1..{self.SMALL_BATCH}, {S}), got {tuple(x.shape)}")
+        if getattr(self, "_pin", None) is None:
+            self._pin = (torch.empty(self.SMALL_BATCH, S, dtype=torch.float32).pin_memory(),
+                         torch.empty(self.SMALL_BATCH, D, dtype=torch.float32).pin_memory())
+        pin_in, pin_out = self._pin
+        if isinstance(x, torch.Tensor) and x.device.type == "cuda":
+            if x.dtype != torch.float32:
+                raise RuntimeError(f"obs: expected float32, got {x.dtype}")
+            src = x if x.stride(1) == 1 else x.contiguous()
+            xp, xrs = N.ptr(src), src.stride(0)
+        else:
+            pin_in[:B].copy_(torch.as_tensor(x, dtype=torch.float32))      # host memcpy into the staging rows
+            xp, xrs = N.ptr(pin_in), S
+        stream = torch.cuda.current_stream(self.device)
+        N.check(self._lib.porl_iql_forward_policy(self._h, xp, xrs, B, N.ptr(pin_out), D, C.c_void_p(stream.cuda_stream)),
+                "porl_iql_forward_policy")
+        stream.synchronize()
+        return pin_out[:B].numpy().copy()
+
     def _free_signals(self):
         for p in (getattr(self, "_signals", None) or []):
             self._lib.porl_signal_destroy(p)

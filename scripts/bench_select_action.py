@@ -16,6 +16,12 @@ for S, H in ((362, 512), (60, 1024)):
     for _ in range(n): a = agent.select_action(x)
     el = time.perf_counter() - t0
     print(f"S={S} H={H}: select_action (B=1, returns numpy) {1e6 * el / n:.1f} us per call")
+    xn = x.cpu().numpy()
+    for _ in range(20): agent.select_action(xn)
+    t0 = time.perf_counter()
+    for _ in range(n): a = agent.select_action(xn)
+    el = time.perf_counter() - t0
+    print(f"    from an ndarray observation: {1e6 * el / n:.1f} us per call")
     from porl_amd import engine as E
     E.prof_enable(True)
     for _ in range(200): agent.select_action(x)

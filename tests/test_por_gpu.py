@@ -442,6 +442,14 @@ def test_small_batch_inference_path_matches_the_batched_kernels(B):
     r1, r2, _, _ = twin_forward(o.P, "vf", x9[:B].cpu().numpy(), 2, False)
     np.testing.assert_allclose(v1.cpu().numpy(), r1, atol=2e-6)
     np.testing.assert_allclose(v2.cpu().numpy(), r2, atol=2e-6)
+    # the rollout path: mean as numpy through pinned host memory, from a device tensor, a CPU tensor or an ndarray
+    want = small.cpu().numpy()
+    for src in (x9[:B], x9[:B].cpu(), x9[:B].cpu().numpy()):
+        got = agent.goal_policy.mean_numpy(src)
+        assert isinstance(got, np.ndarray) and got.dtype == np.float32
+        np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(agent.goal_policy.mean_numpy(x9[0].cpu().numpy()), want[0])
+    np.testing.assert_allclose(agent.goal_policy.mean_numpy(x9.cpu().numpy()), agent.goal_policy(x9).mean.cpu().numpy(), atol=0)
     # strided input rows (a column slice of a packed batch) are read in place
     packed = torch.from_numpy(make_rows(B, 60, 2, seed=4)).to(DEV)
     np.testing.assert_allclose(agent.goal_policy(packed[:, :60]).mean.cpu().numpy(),
