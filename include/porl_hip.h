@@ -289,6 +289,14 @@ typedef struct porl_qnet_variant {
    * the behaviour policy's logits. */
   int32_t td_off;
 } porl_qnet_variant;
+/* learn() on B distinct rows drawn INSIDE the step kernel: batch row b is row perm_{seed,draw}(b) of the n_rows-row replay
+ * arrays, the keyed permutation of porl_sample_indices (same indices, no sampler launch, no index buffer).  Replaces
+ * ReplayBuffer.sample + learn (buffer/replay_buffer.py:64, cql_trainer.py:88-124) for device-resident buffers.
+ * porl_qnet_can_sample: 1 when the engine's network runs on the two-group one-launch kernel. */
+int32_t porl_qnet_can_sample(const porl_qnet* h);
+int porl_qnet_learn_sampled(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions, const float* rewards,
+                            const float* next_states, int64_t n_rs, const float* dones, int64_t n_rows, uint64_t seed,
+                            uint64_t draw, int32_t batch, const porl_qnet_hyper* hp, void* stream);
 int porl_qnet_learn_variant(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions,
                             const float* rewards, const float* next_states, int64_t n_rs, const float* dones,
                             const int64_t* idx, int32_t batch, const porl_qnet_hyper* hp,

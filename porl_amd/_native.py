@@ -27,7 +27,7 @@ SYMBOLS = [
     "porl_qnet_create", "porl_qnet_destroy", "porl_qnet_param_floats", "porl_qnet_tensors",
     "porl_qnet_tensor_info", "porl_qnet_workspace_floats", "porl_qnet_bind", "porl_qnet_load_batch",
     "porl_qnet_cql_backward", "porl_qnet_apply", "porl_qnet_learn", "porl_qnet_sync_target",
-    "porl_qnet_forward", "porl_qnet_forward_loaded", "porl_qnet_backward", "porl_qr_loss", "porl_iqn_quantile_huber", "porl_c51_loss", "porl_reduce_mean", "porl_qnet_penalty", "porl_qnet_learn_indexed", "porl_qnet_one_launch", "porl_qnet_learn_variant",
+    "porl_qnet_forward", "porl_qnet_forward_loaded", "porl_qnet_backward", "porl_qr_loss", "porl_iqn_quantile_huber", "porl_c51_loss", "porl_reduce_mean", "porl_qnet_penalty", "porl_qnet_learn_indexed", "porl_qnet_one_launch", "porl_qnet_learn_variant", "porl_qnet_can_sample", "porl_qnet_learn_sampled",
     "porl_enc_create", "porl_enc_destroy", "porl_enc_param_floats", "porl_enc_stat_floats",
     "porl_enc_workspace_floats", "porl_enc_tensors", "porl_enc_norms", "porl_enc_blocks",
     "porl_enc_tensor_info", "porl_enc_norm_info", "porl_enc_bind", "porl_enc_weights_changed", "porl_enc_forward",
@@ -151,6 +151,10 @@ def _declare(lib):
                                             C.POINTER(QnetVariant), vp]
     lib.porl_qnet_one_launch.argtypes = [vp]
     lib.porl_qnet_one_launch.restype = i32
+    lib.porl_qnet_can_sample.argtypes = [vp]
+    lib.porl_qnet_can_sample.restype = i32
+    lib.porl_qnet_learn_sampled.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, i64, C.c_uint64, C.c_uint64, i32,
+                                            C.POINTER(QnetHyper), vp]
     lib.porl_qnet_sync_target.argtypes = [vp, vp]
     lib.porl_qnet_forward.argtypes = [vp, C.c_int, vp, i64, i32, vp, i64, vp]
     lib.porl_qnet_forward_loaded.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, i64, vp]

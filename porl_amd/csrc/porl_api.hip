@@ -1685,10 +1685,12 @@ static int qnet_forward(porl_qnet* h, int nnets, const float* const* params, con
 
 // gradient of one minibatch in two launches: the fused step kernel (32 rows per block), then the block-order
 // sum of the partial gradients (+ loss statistics)
+struct QnetSampling { int64_t n_rows = 0; uint64_t seed = 0, step = 0; };
+
 static int qnet_fused_backward(porl_qnet* h, const porl_qnet_hyper* hp, int B, const float* states, int64_t s_rs,
                                const float* next_states, int64_t n_rs, const int64_t* actions, const float* rew,
                                const float* done, const int64_t* idx, hipStream_t s, bool with_adam = false,
-                               const porl_qnet_variant* var = nullptr) {
+                               const porl_qnet_variant* var = nullptr, const QnetSampling* samp = nullptr) {
   float* W = h->buf.workspace;
   QnetFusedArgs a = h->fargs;
   a.params = h->buf.params; a.params_tgt = h->buf.params_tgt;
@@ -1716,6 +1718,11 @@ static int qnet_fused_backward(porl_qnet* h, const porl_qnet_hyper* hp, int B, c
   }
   // 16 rows per block while 32-row blocks would leave CUs idle (config 3 at B = 4096: 128 blocks on 256 CUs)
   const bool two = g_qnet_two_groups && h->fused2_lds_w2 > 0;
+  if (samp && samp->n_rows > 0) {
+    if (!two) PORL_FAIL(PORL_ERR_UNSUPPORTED, "in-kernel sampling needs the two-group step kernel");
+    a.samp_n = samp->n_rows; a.samp_seed = samp->seed; a.samp_step = samp->step; a.samp_hb = feistel_half_bits(samp->n_rows);
+    a.idx = nullptr;
+  }
   const bool rows16 = two && g_qnet_rows16 && h->fused16_lds_w2 > 0 && cdiv(B, QF_ROWS) < NUM_CU;
   const int nblk = cdiv(B, rows16 ? 16 : QF_ROWS);
   if (rows16) {
@@ -1961,6 +1968,24 @@ int porl_qnet_learn_indexed(porl_qnet* h, const float* states, int64_t s_rs, con
               "minibatch and use porl_qnet_load_batch + porl_qnet_learn", QF_MAX_W, QF_MAX_LIN);
   return qnet_fused_backward(h, hp, batch, states, s_rs, next_states, n_rs, actions, rewards, dones, idx,
                              (hipStream_t)stream, true);
+}
+
+int32_t porl_qnet_can_sample(const porl_qnet* h) {
+  return h && h->fused_ok && g_qnet_fused && g_qnet_two_groups && h->fused2_lds_w2 > 0 ? 1 : 0;
+}
+
+int porl_qnet_learn_sampled(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions, const float* rewards,
+                            const float* next_states, int64_t n_rs, const float* dones, int64_t n_rows, uint64_t seed,
+                            uint64_t draw, int32_t batch, const porl_qnet_hyper* hp, void* stream) {
+  PORL_TRY(qnet_ready(h, false)); DevGuard _dg(h->device);
+  if (!hp || !states || !actions || !rewards || !next_states || !dones) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
+  if (n_rows < batch || n_rows > (int64_t(1) << 40)) PORL_FAIL(PORL_ERR_INVALID, "need batch <= n_rows <= 2^40");
+  if (!porl_qnet_can_sample(h)) PORL_FAIL(PORL_ERR_UNSUPPORTED, "in-kernel sampling needs the two-group one-launch step kernel");
+  QnetSampling sp;
+  sp.n_rows = n_rows; sp.seed = seed; sp.step = draw;
+  return qnet_fused_backward(h, hp, batch, states, s_rs, next_states, n_rs, actions, rewards, dones, nullptr,
+                             (hipStream_t)stream, true, nullptr, &sp);
 }
 
 int porl_qnet_learn_variant(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions, const float* rewards,

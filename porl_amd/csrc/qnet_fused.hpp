@@ -51,6 +51,10 @@ struct QnetFusedArgs {
   int td_off;                        // 1: no TD term at all (loss = alpha * penalty: the cross-entropy pre-training of
                                      // the behaviour policy, bcq.py:23-47, is logsumexp(z) - z[a] = penalty + ln A)
   unsigned long long* stamps;        // diagnostics: shader-clock stamps of block 0 at the phase boundaries, or null
+  // In-kernel sampling (two-group kernel only): with samp_n > 0 batch row b is replay row perm_{seed,step}(b) of
+  // [0, samp_n) — the keyed Feistel permutation of porl_sample_indices (kernels.hpp: feistel_index) — computed by the
+  // block's first lanes instead of being read from `idx`: no sampler launch, no index round trip at kernel entry.
+  long samp_n; unsigned long long samp_seed, samp_step; int samp_hb;
 };
 
 typedef float qf_f32x16 __attribute__((ext_vector_type(16)));
@@ -569,10 +573,17 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
 // branch per slot — `if (u * 256 < total)`, `idx ? idx[b] : b` — the compiler closed every slot with s_waitcnt
 // vmcnt(0): nine dependent round trips to HBM at kernel entry instead of two, ~12 k cycles.)
 struct QfInput { long row[QF_XREGS]; float v[QF_XREGS]; };
-__device__ __forceinline__ void qf_input_rows(QfInput& in, int ld, const int64_t* idx, int row0, int B, int t, int rows = QF_ROWS) {
+__device__ __forceinline__ void qf_input_rows(QfInput& in, int ld, const int64_t* idx, int row0, int B, int t, int rows = QF_ROWS,
+                                              const long* lds_rows = nullptr) {
   const int total = rows * ld;
   const float inv_ld = 1.0f / (float)ld;
-  if (idx) {
+  if (lds_rows) {                                     // sampled in the kernel: the block's row numbers sit in LDS
+#pragma unroll
+    for (int u = 0; u < QF_XREGS; ++u) {
+      const int i = u * 256 + t;
+      in.row[u] = lds_rows[qf_div(i < total ? i : 0, inv_ld)];
+    }
+  } else if (idx) {
 #pragma unroll
     for (int u = 0; u < QF_XREGS; ++u) {
       const int i = u * 256 + t;
@@ -818,10 +829,20 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
   // image and the loss stage's per-row scalars (lanes 0..31 of wave 0; see the one-group kernel) while they are in flight.
   // Group 0 gathers s' (for the target net), group 1 gathers s.
   QfInput xin;
-  qf_input_rows(xin, ldx, a.idx, row0, a.B, tg, ROWS);
+  __shared__ long srow[QF_ROWS];
+  const bool sampled = a.samp_n > 0;
+  if (sampled) {
+    if (t < ROWS) {
+      const int b = row0 + t;
+      srow[t] = b < a.B ? (long)feistel_index(a.samp_n, b, a.samp_seed, a.samp_step, a.samp_hb) : 0L;
+    }
+    dma(0, wl);                                      // (in flight across the barrier: it is an asm statement)
+    qf_barrier();
+  }
+  qf_input_rows(xin, ldx, a.idx, row0, a.B, tg, ROWS, sampled ? srow : nullptr);
   const int my_row = row0 + (t < ROWS ? t : 0);
-  const long my_src = my_row < a.B ? (a.idx ? a.idx[my_row] : (long)my_row) : 0L;
-  dma(0, wl);
+  const long my_src = sampled ? srow[t < ROWS ? t : 0] : (my_row < a.B ? (a.idx ? a.idx[my_row] : (long)my_row) : 0L);
+  if (!sampled) dma(0, wl);
   qf_input_load(xin, ldx, grp ? a.states : a.next_states, grp ? a.s_rs : a.n_rs, row0, a.B, a.dims[0], tg, ROWS);
   const int row_act = (int)a.actions[my_src];
   const float row_rew = a.rew[my_src], row_done = a.done[my_src];

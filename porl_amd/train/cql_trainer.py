@@ -133,6 +133,29 @@ class QnetEngine:
                                                       N.current_stream_ptr(self.device)), "porl_qnet_learn_variant")
         return B
 
+    def learn_sampled(self, hp, states, actions, rewards, next_states, dones, n_rows, batch, seed, draw):
+        """learn() on `batch` distinct rows of the first `n_rows` rows of device-resident replay arrays, drawn inside
+        the step kernel (the indices of engine.sample_indices(n_rows, batch, seed, draw), never materialised)."""
+        self._ensure_bound()
+        if batch > self.cfg.max_batch:
+            raise RuntimeError(f"batch {batch} exceeds engine max_batch {self.cfg.max_batch}")
+        for name, x, dt in (("states", states, torch.float32), ("next_states", next_states, torch.float32),
+                            ("actions", actions, torch.int64), ("rewards", rewards, torch.float32),
+                            ("dones", dones, torch.float32)):
+            if x.dtype != dt or x.device != self.device or not x.is_contiguous() or x.shape[0] < n_rows:
+                raise RuntimeError(f"{name}: need a contiguous {dt} tensor of >= {n_rows} rows on {self.device}")
+        if states.shape[1:].numel() != self.cfg.state_dim or next_states.shape != states.shape:
+            raise RuntimeError("replay arrays do not match the network's state_dim")
+        N.check(self._lib.porl_qnet_learn_sampled(self._h, N.ptr(states), self.cfg.state_dim, N.ptr(actions), N.ptr(rewards),
+                                                  N.ptr(next_states), self.cfg.state_dim, N.ptr(dones), int(n_rows),
+                                                  int(seed), int(draw), int(batch), C.byref(hp),
+                                                  N.current_stream_ptr(self.device)), "porl_qnet_learn_sampled")
+        return batch
+
+    @property
+    def can_sample(self):
+        return bool(self._lib.porl_qnet_can_sample(self._h))
+
     def sync_target(self):
         self._ensure_bound()
         N.check(self._lib.porl_qnet_sync_target(self._h, N.current_stream_ptr(self.device)), "porl_qnet_sync_target")
@@ -252,18 +275,24 @@ class CQLTrainer:
             raise ValueError("Cannot take a larger sample than population when 'replace=False'")
         rb._sync_mirror()
         self._draws = getattr(self, "_draws", 0)
-        idx = E.sample_indices(rb.size, self.batch_size, seed, self._draws, device=self.device)
+        draw = self._draws
         self._draws += 1
         eng, ex = self._engine, self._exchange
         if ex.world_size > 1 or not eng.fused:
+            idx = E.sample_indices(rb.size, self.batch_size, seed, draw, device=self.device)
             return self.learn_on(*rb.gather_device(idx))
-        # one-launch path: the step kernel gathers rows idx of the device mirror itself
+        # one-launch path: the step kernel draws the rows itself (or gathers rows idx of the device mirror)
         m = rb._mirror
         self.optimizer.step_count += 1
         g = self.optimizer.param_groups[0]
-        hp = eng.hyper(self.gamma, float(self.alpha), 1.0 / idx.numel(), self.optimizer.step_count, g["lr"], g["betas"],
+        hp = eng.hyper(self.gamma, float(self.alpha), 1.0 / self.batch_size, self.optimizer.step_count, g["lr"], g["betas"],
                        g["eps"])
-        eng.learn_indexed(hp, m["states"], m["actions"], m["rewards"], m["next_states"], m["dones"], idx)
+        if eng.can_sample:
+            eng.learn_sampled(hp, m["states"], m["actions"], m["rewards"], m["next_states"], m["dones"], rb.size,
+                              self.batch_size, seed, draw)
+        else:
+            idx = E.sample_indices(rb.size, self.batch_size, seed, draw, device=self.device)
+            eng.learn_indexed(hp, m["states"], m["actions"], m["rewards"], m["next_states"], m["dones"], idx)
         if self.async_losses:
             return eng.stats[:3]
         loss, self.last_td_loss, self.last_cql_penalty = eng.stats[:3].tolist()
