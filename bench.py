@@ -394,6 +394,8 @@ def main():
         E.tune_set("iql_pad_value", v[0]); E.tune_set("iql_pad_policy", v[1])
         if len(v) > 2:
             E.tune_set("iql_pad_min_blocks", v[2])
+        if len(v) > 3:
+            E.tune_set("iql_pad_min_k", v[3])
     if os.environ.get("PORL_GEMM_LDS_PAD"):                    # A/B: fewer co-resident GEMM blocks per CU (placement knob)
         E.tune_set("gemm_lds_pad", int(os.environ["PORL_GEMM_LDS_PAD"]))
     if os.environ.get("PORL_VBWD_TILE"):                       # A/B: tile of the value backward in pipelined mode

@@ -254,11 +254,11 @@ int pick_splitk(int M, int N, int K, int nprob, int bm, int bn) {
 // (with a 45 KB pad, i.e. two blocks and NO LDS left over, the update is slower than unpadded: 3 044 vs 3 106).
 // none 3 106; every GEMM launch 3 256; value phase only 3 248; policy phase only 3 065; only launches of >= 1 000 blocks
 // 3 270.  Default: the value phase's launches of at least 4 blocks per CU.
-int g_iql_pad_value = 18432, g_iql_pad_policy = 0, g_iql_pad_min_blocks = 4 * NUM_CU;
+int g_iql_pad_value = 18432, g_iql_pad_policy = 0, g_iql_pad_min_blocks = 4 * NUM_CU, g_iql_pad_min_k = 0;
 struct PadScope {
   int saved, saved_min;
-  PadScope() : saved(gemm_lds_pad()), saved_min(gemm_lds_pad_min_blocks()) {
-    if (g_short_blocks && saved == 0) {
+  explicit PadScope(const GemmGroup& g) : saved(gemm_lds_pad()), saved_min(gemm_lds_pad_min_blocks()) {
+    if (g_short_blocks && saved == 0 && g.nprob > 0 && g.p[0].K >= g_iql_pad_min_k) {
       gemm_lds_pad() = g_phase[0] == 'P' ? g_iql_pad_policy : g_iql_pad_value;
       gemm_lds_pad_min_blocks() = g_iql_pad_min_blocks;
     }
@@ -267,7 +267,7 @@ struct PadScope {
 };
 
 int launch_group(GemmGroup& g, int tile, hipStream_t s) {
-  PadScope _pad;
+  PadScope _pad(g);
   double flops = 0.0, bytes = 0.0;
   std::string label;
   if (g_prof.on) {
@@ -1353,6 +1353,7 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "iql_pad_value")) { g_iql_pad_value = std::max(0, value); return PORL_OK; }
   if (!strcmp(key, "iql_pad_policy")) { g_iql_pad_policy = std::max(0, value); return PORL_OK; }
   if (!strcmp(key, "iql_pad_min_blocks")) { g_iql_pad_min_blocks = std::max(0, value); return PORL_OK; }
+  if (!strcmp(key, "iql_pad_min_k")) { g_iql_pad_min_k = std::max(0, value); return PORL_OK; }
   if (!strcmp(key, "qnet_fused")) { g_qnet_fused = value != 0; return PORL_OK; }
   if (!strcmp(key, "qnet_two_groups")) { g_qnet_two_groups = value != 0; return PORL_OK; }
   if (!strcmp(key, "qnet_rows16")) { g_qnet_rows16 = value != 0; return PORL_OK; }
