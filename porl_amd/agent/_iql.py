@@ -242,10 +242,7 @@ class IqlAgentBase(nn.Module):
         else:
             if world > 1:
                 ex.allreduce_sum_(eng.grads_vf)
-            if use_sig:
-                eng.wait_signal(eng.SIG_FWD, seq - 1, main)
-            else:
-                eng.wait_values_read()         # the PREVIOUS update's policy phase has read the old value nets
+            eng.wait_values_read()             # the PREVIOUS update's policy phase has read the old value nets
             eng.value_apply(hp)
         # ---- policy phase -------------------------------------------------------------------------------------------
         if pipelined:
@@ -278,7 +275,7 @@ class IqlAgentBase(nn.Module):
                 if not use_sig:                               # (signal mode: join() records its own event when needed)
                     ev_p.record(side)
             # the next value Adam waits for ev_f only; readers of the agent (flush) wait for ev_p
-            eng._values_read, eng._policy_done = (None if use_sig else ev_f), (True if use_sig else ev_p)
+            eng._values_read, eng._policy_done = (("sig", seq) if use_sig else ev_f), (True if use_sig else ev_p)
             eng._slot_users = eng._slot_users[1:] + [None if use_sig else ev_p]
         else:
             eng.policy_backward(hp)

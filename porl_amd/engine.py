@@ -112,7 +112,9 @@ class IqlEngine:
         """Order the current stream behind the forward half of the outstanding policy phase: after it the value
         parameters may be overwritten (the rest of that phase only touches policy state and its own scratch)."""
         ev, self._values_read = self._values_read, None
-        if ev is not None:
+        if isinstance(ev, tuple):                      # signal mode: ("sig", update number of that policy phase)
+            self.wait_signal(self.SIG_FWD, ev[1], torch.cuda.current_stream(self.device))
+        elif ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
 
     def set_mode(self, mode):
