@@ -367,6 +367,37 @@ def test_pipelined_updates_are_bit_identical_to_back_to_back_updates():
     np.testing.assert_array_equal(hist[:, :2].cpu().numpy(), np.array(want, dtype=np.float32))
 
 
+@pytest.mark.parametrize("sync", ["signal", "event"])
+def test_pipelined_updates_at_the_headline_size_are_bit_identical(sync, monkeypatch):
+    """The same property at BASELINE config 2 (H = 1024, B = 1024, device sampler), where the two streams really
+    overlap: 64x64 short blocks, the value phase's 1 024-block launches at two blocks per CU, three staging slots, the
+    streams ordered by signal counters (or events).  40 pipelined updates against 40 one-stream updates: every
+    parameter, target parameter and Adam moment equal bit for bit, and so is the loss history."""
+    import porl_amd.agent._iql as iql
+    from porl_amd.buffer.replay_buffer import PackedReplay
+    monkeypatch.setattr(iql, "_PIPE_SYNC", sync)
+    S, A, B, H, K = 60, 2, 1024, 1024, 40
+    rows = make_rows(50_000, S, A, seed=11)
+    out = []
+    for pipe in (False, True):
+        agent = _make_por(S, H, 2, B)
+        agent.async_losses = True
+        agent.pipeline = pipe
+        rp = PackedReplay(rows, S, A, DEV, seed=3)
+        hist = torch.zeros(K, 8, device=DEV)
+        for k in range(K):
+            agent._engine.set_stats(hist[k])
+            agent.update_from_replay(rp, B)
+        agent.flush()
+        torch.cuda.synchronize()
+        eng = agent._engine
+        out.append([t.clone() for t in (eng.params_vf, eng.params_tgt, eng.params_pol, eng.adam_m_vf, eng.adam_v_vf,
+                                        eng.adam_m_pol, eng.adam_v_pol, hist[:, :3])])
+    for a, b, what in zip(out[0], out[1], ("vf", "target", "policy", "m_vf", "v_vf", "m_pol", "v_pol", "losses")):
+        assert torch.equal(a, b), what
+    assert torch.isfinite(out[0][-1]).all()
+
+
 def test_engine_on_a_non_current_device_guard():
     """The C entry points launch on the device that owns the engine's buffers, and the stream handed over is torch's
     current stream OF THAT device — whatever the thread's current device is (_native.py:202)."""
