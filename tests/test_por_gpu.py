@@ -367,8 +367,8 @@ def test_pipelined_updates_are_bit_identical_to_back_to_back_updates():
     np.testing.assert_array_equal(hist[:, :2].cpu().numpy(), np.array(want, dtype=np.float32))
 
 
-@pytest.mark.parametrize("sync", ["signal", "event"])
-def test_pipelined_updates_at_the_headline_size_are_bit_identical(sync, monkeypatch):
+@pytest.mark.parametrize("sync,ln", [("signal", False), ("event", False), ("signal", True)])
+def test_pipelined_updates_at_the_headline_size_are_bit_identical(sync, ln, monkeypatch):
     """The same property at BASELINE config 2 (H = 1024, B = 1024, device sampler), where the two streams really
     overlap: 64x64 short blocks, the value phase's 1 024-block launches at two blocks per CU, three staging slots, the
     streams ordered by signal counters (or events).  40 pipelined updates against 40 one-stream updates: every
@@ -380,7 +380,7 @@ def test_pipelined_updates_at_the_headline_size_are_bit_identical(sync, monkeypa
     rows = make_rows(50_000, S, A, seed=11)
     out = []
     for pipe in (False, True):
-        agent = _make_por(S, H, 2, B)
+        agent = _make_por(S, H, 2, B, ln=ln)
         agent.async_losses = True
         agent.pipeline = pipe
         rp = PackedReplay(rows, S, A, DEV, seed=3)
