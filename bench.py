@@ -385,6 +385,8 @@ def main():
     agent.pipeline = not a.no_pipeline
     if os.environ.get("PORL_IQL_FOLD") == "0":                 # A/B: slab combines as separate launches
         E.tune_set("iql_fold", 0)
+    if os.environ.get("PORL_L0_KERNEL") == "0":                # A/B: input layers through the grouped GEMM
+        E.tune_set("l0_kernel", 0)
     for i, v in enumerate(os.environ.get("PORL_TILE_MAP", "").split(",")):      # A/B: e.g. "0,1,2,3" = round-1 choice
         if v.strip():
             E.tune_set("tile_map%d" % i, int(v))

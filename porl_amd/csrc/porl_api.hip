@@ -14,6 +14,7 @@
 #include "gemm_f32.hpp"
 #include "gemm_bf16.hpp"
 #include "kernels.hpp"
+#include "l0_fwd.hpp"
 #include "qnet_fused.hpp"
 #include "per_tree.hpp"
 #include "dist_losses.hpp"
@@ -117,6 +118,7 @@ int g_tile_map[4] = {TILE_64x128, TILE_64x64, TILE_64x128, TILE_64x64};
 int g_tile_map_short[4] = {TILE_64x64, TILE_64x64, TILE_64x128, TILE_64x64};
 thread_local bool g_short_blocks = false;       // set by the IQL entry points from the handle's mode
 int g_vbwd_tile_short = -1;   // porl_tune_set("vbwd_tile_short", t): tile of the value nets' hidden-layer backward in short-block mode (A/B)
+int g_l0_kernel = 1;        // porl_tune_set("l0_kernel", 0): input layers (K <= 64) through the grouped GEMM instead of l0_fwd_kernel (A/B, bit-identical)
 int g_l0_tile = -1;          // porl_tune_set("l0_tile", t): tile override for the K <= 128 forward layers of the IQL step (A/B)
 int g_iql_fold = 1;          // porl_tune_set("iql_fold", 0): porl_iql_step keeps the slab combines as launches of their own (A/B)
 int g_enc_bn_sweep = 0;      // porl_tune_set("enc_bn_sweep", 1): BatchNorm + ReLU of the MLP blocks as a separate sweep (cross-check)
@@ -359,6 +361,22 @@ struct FwdNet {
 int fwd_hidden_layer(porl_iql* h, const FwdNet* nets, int nnets, int B, int K, bool last, int* parts_out,
                      hipStream_t s) {
   const int H = h->cfg.hidden_dim;
+  // input layer (K = obs_dim <= 64), plain Linear + ReLU with a stored output: its own one-round kernel (l0_fwd.hpp)
+  if (g_l0_kernel && K <= L0_KP && nnets <= L0_MAX_NETS) {
+    L0Args a{};
+    a.nnets = nnets; a.B = B; a.H = H; a.K = K; a.ldw = K; a.ldo = h->Hp;
+    bool plain = true;
+    for (int n = 0; n < nnets; ++n) {
+      plain = plain && !nets[n].ln_g && nets[n].out && !(last && nets[n].headw);
+      a.net[n] = L0Net{nets[n].in, nets[n].W, nets[n].b, nets[n].out, nets[n].ldin};
+    }
+    if (plain && l0_fwd_supported(a)) {
+      if (parts_out) *parts_out = head_parts(H, 0);
+      ProfScope ps("l0_fwd_kernel", s, 2.0 * nnets * B * (double)H * K, 4.0 * nnets * ((double)B * K + (double)H * K + (double)B * H));
+      PORL_HIP(launch_l0_fwd(a, s));
+      return 0;
+    }
+  }
   GemmGroup g{};
   g.nprob = nnets;
   bool any_ln = false;
@@ -1362,6 +1380,7 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "enc_bn_sweep")) { g_enc_bn_sweep = value != 0; return PORL_OK; }
   if (!strcmp(key, "iql_fold")) { g_iql_fold = value != 0; return PORL_OK; }
   if (!strcmp(key, "l0_tile")) { g_l0_tile = value; return PORL_OK; }
+  if (!strcmp(key, "l0_kernel")) { g_l0_kernel = value != 0; return PORL_OK; }
   if (!strcmp(key, "vbwd_tile_short")) { g_vbwd_tile_short = value; return PORL_OK; }
   if (!strncmp(key, "tile_map_short", 14) && key[14] >= '0' && key[14] <= '3' && !key[15] && value >= 0 && value < TILE_COUNT) {
     g_tile_map_short[key[14] - '0'] = value;

@@ -44,6 +44,20 @@ if os.environ.get("SPINMODE") == "mem":
     for it in range(int(os.environ.get("SPINIT", "1000"))):
         E.adam_ema(bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], 1e-4, it + 1, ema_beta=0.005)
     torch.cuda.synchronize()
+if os.environ.get("SPINMODE") in ("two", "twosmall"):
+    # two streams at once, no agent: short-block GEMMs on both (and sweeps on the second), or only tiny kernels on both
+    small = os.environ["SPINMODE"] == "twosmall"
+    sa, sb = torch.randn(4096, 1024, device=dev), torch.randn(1024, 1024, device=dev)
+    sc, sc2 = torch.empty(4096, 1024, device=dev), torch.empty(4096, 1024, device=dev)
+    bufs = [torch.zeros(4_200_000 if not small else 4096, device=dev) for _ in range(5)]
+    side = torch.cuda.Stream(device=dev)
+    M = 64 if small else 4096
+    for it in range(int(os.environ.get("SPINIT", "150"))):
+        E.gemm_f32(0, sa, sb, M, 1024, 1024, 1024, 1024, sc, 1024, tile=3)
+        with torch.cuda.stream(side):
+            E.gemm_f32(0, sa, sb, M, 1024, 1024, 1024, 1024, sc2, 1024, tile=3)
+            E.adam_ema(bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], 1e-4, it + 1, ema_beta=0.005)
+    torch.cuda.synchronize()
 if os.environ.get("SPINMODE") == "agent":
     torch.manual_seed(1)
     scratch = POR(args, max_steps=1000, tau=0.9, alpha=10.0, device=dev)

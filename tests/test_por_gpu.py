@@ -485,3 +485,31 @@ def test_small_batch_inference_path_matches_the_batched_kernels(B):
     packed = torch.from_numpy(make_rows(B, 60, 2, seed=4)).to(DEV)
     np.testing.assert_allclose(agent.goal_policy(packed[:, :60]).mean.cpu().numpy(),
                                agent.goal_policy(packed[:, :60].contiguous()).mean.cpu().numpy(), atol=0)
+
+
+@pytest.mark.parametrize("S,H,B", [(60, 1024, 1024), (20, 48, 50), (64, 200, 130), (8, 132, 64)])
+def test_input_layer_kernel_is_bit_identical_to_the_grouped_gemm(S, H, B):
+    """csrc/l0_fwd.hpp: the K = obs_dim <= 64 input layers run on a one-round kernel of their own; it reproduces the
+    grouped GEMM's MFMA chain (same k order, zero padding, bias, ReLU), so every loss and parameter of a run equals the
+    run with porl_tune_set("l0_kernel", 0) bit for bit — at the headline shape and at ragged ones (rows and columns
+    that do not fill a 64 x 128 tile, K below and at the 64 limit)."""
+    from porl_amd import _native as N
+    rows = torch.from_numpy(make_rows(3 * B, S, 2, seed=21)).to(DEV)
+    out = []
+    try:
+        for use in (1, 0):
+            N.check(N.lib().porl_tune_set(b"l0_kernel", use), "porl_tune_set")
+            agent = _make_por(S, H, 2, B)
+            losses = []
+            for k in range(3):
+                s, r, sp, d, a = split_rows(rows[k * B:(k + 1) * B], S, 2)
+                losses.append(agent.por_residual_update(s, sp, r, d))
+            both = agent.vf.both(rows[:5, :S].contiguous())
+            out.append((losses, [v.clone() for v in agent.state_dict().values()], [b.clone() for b in both]))
+    finally:
+        N.check(N.lib().porl_tune_set(b"l0_kernel", 1), "porl_tune_set")
+    assert out[0][0] == out[1][0]
+    for x, y in zip(out[0][1], out[1][1]):
+        assert torch.equal(x, y)
+    for x, y in zip(out[0][2], out[1][2]):
+        assert torch.equal(x, y)
