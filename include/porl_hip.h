@@ -440,6 +440,16 @@ int porl_signal_create(void** out);
 int porl_signal_destroy(void* sig);
 int porl_signal_write(void* sig, uint64_t value, void* stream);
 int porl_signal_wait_ge(void* sig, uint64_t value, void* stream);
+/* One pipelined update (sampled minibatch) from one call: value phase on main_stream, policy phase on side_stream,
+ * ordered by the three counters (value Adam done / policy forward half done / policy phase done) exactly as
+ * porl_amd/agent/_iql.py issues the phase calls — reference agent/por.py:73-112 (one update), por_train.py:71-82 (the
+ * loop that calls it).  seq = update number (>= 1, growing); wait_policy_seq / wait_fwd_seq = counter values the main
+ * stream waits for before loading the batch / before the value Adam (0 = no wait); write_policy != 0 publishes seq on
+ * sig_policy at the end.  The engine must be in PORL_IQL_MODE_TWO_SLOTS | PORL_IQL_MODE_FOLD_COMBINE mode. */
+int porl_iql_update_pipelined(porl_iql* h, const porl_iql_hyper* hp, int32_t batch, const float* rows, int64_t row_stride,
+                              int64_t n_rows, int32_t act_dim, int32_t target_is_action, uint64_t seed, uint64_t step,
+                              void* sig_value, void* sig_fwd, void* sig_policy, uint64_t seq, uint64_t wait_policy_seq,
+                              uint64_t wait_fwd_seq, int32_t write_policy, void* main_stream, void* side_stream);
 
 /* Per-launch timing with HIP events on the launch stream (off by default; adds two event records per
  * kernel).  porl_prof_read synchronises the device and returns the number of entries filled. */

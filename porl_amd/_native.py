@@ -23,7 +23,7 @@ SYMBOLS = [
     "porl_iql_policy_apply", "porl_iql_step", "porl_iql_policy_prefetch", "porl_iql_forward_value", "porl_iql_forward_policy",
     "porl_gemm_f32", "porl_adam_ema", "porl_ema", "porl_softmax_mask", "porl_gather_rows", "porl_sample_indices", "porl_epoch_indices", "porl_per_update", "porl_per_sample",
     "porl_prof_enable", "porl_prof_read", "porl_tune_set", "porl_tune_set_ptr", "porl_state2costmap",
-    "porl_signal_create", "porl_signal_destroy", "porl_signal_write", "porl_signal_wait_ge",
+    "porl_signal_create", "porl_signal_destroy", "porl_signal_write", "porl_signal_wait_ge", "porl_iql_update_pipelined",
     "porl_qnet_create", "porl_qnet_destroy", "porl_qnet_param_floats", "porl_qnet_tensors",
     "porl_qnet_tensor_info", "porl_qnet_workspace_floats", "porl_qnet_bind", "porl_qnet_load_batch",
     "porl_qnet_cql_backward", "porl_qnet_apply", "porl_qnet_learn", "porl_qnet_sync_target",
@@ -131,6 +131,8 @@ def _declare(lib):
     lib.porl_signal_destroy.argtypes = [vp]
     lib.porl_signal_write.argtypes = [vp, C.c_uint64, vp]
     lib.porl_signal_wait_ge.argtypes = [vp, C.c_uint64, vp]
+    lib.porl_iql_update_pipelined.argtypes = [vp, C.POINTER(IqlHyper), i32, vp, i64, i64, i32, i32, C.c_uint64, C.c_uint64,
+                                              vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, i32, vp, vp]
     lib.porl_state2costmap.argtypes = [vp, i64, i32, i32, i32, vp, vp]
     lib.porl_qnet_create.argtypes = [C.POINTER(QnetCfg), C.POINTER(vp)]
     lib.porl_qnet_destroy.argtypes = [vp]

@@ -17,6 +17,12 @@ from ..parallel import GradExchange
 # cross-stream ordering of the pipelined update: "signal" = counters in signal memory (engine.py: 3 380 vs 3 300 updates/s),
 # "event" = event record / stream-wait-event pairs (A/B, and the fallback where wait-value operations are missing)
 _PIPE_SYNC = __import__("os").environ.get("PORL_PIPE_SYNC", "signal")
+# The whole pipelined update from one native call (porl_iql_update_pipelined): "1" always, "0" never, default "auto" =
+# only for small networks, where the host's issue rate is the bound (measured, updates/s, phase calls -> one call:
+# H=256 B=256 9 470 -> 10 990; H=256 B=1024 8 160 -> 8 060; H=1024 B=1024 3 365 -> 3 315 — at GPU-bound sizes the
+# denser issue order shifts the two streams against each other and costs ~1 %).
+_PIPE_ONECALL = __import__("os").environ.get("PORL_PIPE_ONECALL", "auto")
+_ONECALL_MAX_WORK = 32 << 20        # batch * hidden_dim^2 below which the update is host-bound
 
 class ArenaAdam:
     """torch.optim.Adam look-alike over one flat parameter group of the engine.
@@ -208,6 +214,25 @@ class IqlAgentBase(nn.Module):
         eng.set_mode(((IqlEngine.MODE_TWO_SLOTS | IqlEngine.MODE_SHORT_BLOCKS) if pipelined else 0) |
                      (IqlEngine.MODE_FOLD_COMBINE if world == 1 else 0))
         use_sig = pipelined and _PIPE_SYNC in ("signal", "signal2") and eng.signals() is not None
+        onecall = _PIPE_ONECALL is True or _PIPE_ONECALL == "1" or (
+            _PIPE_ONECALL == "auto" and (batch or 0) * eng.cfg.hidden_dim ** 2 <= _ONECALL_MAX_WORK)
+        if use_sig and world == 1 and replay is not None and onecall:
+            # the whole update from one native call (csrc: porl_iql_update_pipelined): the same operations on the same
+            # two streams in the same order as the phase calls below, without ~12 trips through ctypes per update
+            eng._seq += 1
+            seq = eng._seq
+            v_opt.step_count += 1
+            p_opt.step_count += 1
+            hp = self._hyper(batch, v_opt, p_opt)
+            vr = eng._values_read
+            eng.update_pipelined(hp, replay, batch, seq,
+                                 wait_policy_seq=max(0, seq - eng.SLOTS) if _PIPE_SYNC == "signal" else 0,
+                                 wait_fwd_seq=vr[1] if isinstance(vr, tuple) else 0,
+                                 write_policy=_PIPE_SYNC == "signal")
+            replay.draws += 1
+            eng._values_read, eng._policy_done = ("sig", seq), True
+            sched.step()
+            return self._losses()
         if use_sig:
             main = torch.cuda.current_stream(eng.device)
             eng._seq += 1

@@ -1425,6 +1425,38 @@ int porl_signal_wait_ge(void* sig, uint64_t value, void* stream) {
   return PORL_OK;
 }
 
+// One pipelined update from ONE call: what porl_amd/agent/_iql.py:_full_update issues in signal mode on a single GPU —
+// value phase on `main_stream`, policy phase on `side_stream`, ordered by the three counters — without a round trip
+// through the caller's language per phase (the Python sequence costs ~110 us of host time per update, which is what
+// bounds small configurations; this entry is ~20 launches back to back).  Same launches, same order per stream, same
+// results as the phase calls.
+int porl_iql_update_pipelined(porl_iql* h, const porl_iql_hyper* hp, int32_t batch, const float* rows, int64_t row_stride,
+                              int64_t n_rows, int32_t act_dim, int32_t target_is_action, uint64_t seed, uint64_t step,
+                              void* sig_value, void* sig_fwd, void* sig_policy, uint64_t seq, uint64_t wait_policy_seq,
+                              uint64_t wait_fwd_seq, int32_t write_policy, void* main_stream, void* side_stream) {
+  PORL_TRY(check_ready(h, false));
+  if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
+  if (!sig_value || !sig_fwd || !sig_policy || seq < 1) PORL_FAIL(PORL_ERR_INVALID, "three signal counters and seq >= 1 are required");
+  if (main_stream == side_stream) PORL_FAIL(PORL_ERR_INVALID, "the two phases need two streams");
+  if (!(h->mode & PORL_IQL_MODE_TWO_SLOTS) || !(h->mode & PORL_IQL_MODE_FOLD_COMBINE))
+    PORL_FAIL(PORL_ERR_INVALID, "pipelined updates need PORL_IQL_MODE_TWO_SLOTS | PORL_IQL_MODE_FOLD_COMBINE");
+  // the staging slot loaded next was last read by the policy phase PORL_IQL_SLOTS updates ago
+  if (wait_policy_seq) PORL_TRY(porl_signal_wait_ge(sig_policy, wait_policy_seq, main_stream));
+  PORL_TRY(porl_iql_load_batch_sampled(h, batch, rows, row_stride, n_rows, act_dim, target_is_action, seed, step, nullptr, main_stream));
+  PORL_TRY(porl_iql_value_backward(h, hp, main_stream));
+  // the previous update's policy phase has read the old value nets
+  if (wait_fwd_seq) PORL_TRY(porl_signal_wait_ge(sig_fwd, wait_fwd_seq, main_stream));
+  PORL_TRY(porl_iql_value_apply(h, hp, main_stream));
+  PORL_TRY(porl_signal_write(sig_value, seq, main_stream));
+  PORL_TRY(porl_signal_wait_ge(sig_value, seq, side_stream));
+  PORL_TRY(porl_iql_policy_forward(h, hp, side_stream));
+  PORL_TRY(porl_signal_write(sig_fwd, seq, side_stream));
+  PORL_TRY(porl_iql_policy_backward(h, hp, side_stream));
+  PORL_TRY(porl_iql_policy_apply(h, hp, side_stream));
+  if (write_policy) PORL_TRY(porl_signal_write(sig_policy, seq, side_stream));
+  return PORL_OK;
+}
+
 int porl_tune_set_ptr(const char* key, void* ptr) {
   if (!key) PORL_FAIL(PORL_ERR_INVALID, "null key");
   if (!strcmp(key, "qnet_stamps")) { g_qnet_stamps = (unsigned long long*)ptr; return PORL_OK; }

@@ -268,6 +268,21 @@ class IqlEngine:
     def policy_apply(self, hp): self._phase("porl_iql_policy_apply", hp)
     def step(self, hp): self._phase("porl_iql_step", hp)
 
+    def update_pipelined(self, hp, replay, batch, seq, wait_policy_seq, wait_fwd_seq, write_policy):
+        """One pipelined update on rows drawn from `replay` (PackedReplay): value phase on the current stream, policy
+        phase on the side stream, ordered by the signal counters — include/porl_hip.h:porl_iql_update_pipelined."""
+        rows = replay.rows
+        if rows.device != self.device or rows.dtype != torch.float32 or rows.dim() != 2 or rows.stride(1) != 1:
+            raise RuntimeError("replay rows must be a 2-D fp32 tensor on the engine's device")
+        sig = self.signals()
+        N.check(self._lib.porl_iql_update_pipelined(
+            self._h, C.byref(hp), batch, N.ptr(rows), rows.stride(0), rows.shape[0], replay.act_dim,
+            int(self.cfg.weight_mode == 1), replay.seed & 0xFFFFFFFFFFFFFFFF, replay.draws,
+            sig[self.SIG_VALUE], sig[self.SIG_FWD], sig[self.SIG_POLICY], int(seq), int(wait_policy_seq),
+            int(wait_fwd_seq), int(bool(write_policy)), N.current_stream_ptr(self.device),
+            C.c_void_p(self.side_stream().cuda_stream)), "porl_iql_update_pipelined")
+        self.last_batch = batch
+
     def policy_prefetch(self):
         N.check(self._lib.porl_iql_policy_prefetch(self._h, N.current_stream_ptr(self.device)), "porl_iql_policy_prefetch")
 

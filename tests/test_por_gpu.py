@@ -367,7 +367,7 @@ def test_pipelined_updates_are_bit_identical_to_back_to_back_updates():
     np.testing.assert_array_equal(hist[:, :2].cpu().numpy(), np.array(want, dtype=np.float32))
 
 
-@pytest.mark.parametrize("sync,ln", [("signal", False), ("event", False), ("signal", True)])
+@pytest.mark.parametrize("sync,ln", [("signal", False), ("event", False), ("signal", True), ("signal/phase-calls", False)])
 def test_pipelined_updates_at_the_headline_size_are_bit_identical(sync, ln, monkeypatch):
     """The same property at BASELINE config 2 (H = 1024, B = 1024, device sampler), where the two streams really
     overlap: 64x64 short blocks, the value phase's 1 024-block launches at two blocks per CU, three staging slots, the
@@ -375,7 +375,10 @@ def test_pipelined_updates_at_the_headline_size_are_bit_identical(sync, ln, monk
     parameter, target parameter and Adam moment equal bit for bit, and so is the loss history."""
     import porl_amd.agent._iql as iql
     from porl_amd.buffer.replay_buffer import PackedReplay
-    monkeypatch.setattr(iql, "_PIPE_SYNC", sync)
+    # "signal" issues the whole update from one native call (porl_iql_update_pipelined); ".../phase-calls" keeps the
+    # phase-by-phase sequence from Python
+    monkeypatch.setattr(iql, "_PIPE_SYNC", sync.split("/")[0])
+    monkeypatch.setattr(iql, "_PIPE_ONECALL", "/" not in sync)
     S, A, B, H, K = 60, 2, 1024, 1024, 40
     rows = make_rows(50_000, S, A, seed=11)
     out = []
