@@ -68,6 +68,8 @@ if os.environ.get("SPINMODE") == "agent":
         scratch._engine.set_stats(sl); scratch.update_from_replay(replay, B)
     scratch.flush()
     torch.cuda.synchronize()
+if os.environ.get("MAIN_PRIORITY"):     # run the update with a high-priority caller stream (the side stream stays normal)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["MAIN_PRIORITY"])))
 WARM = int(os.environ.get("WARM", "5"))
 for i in range(WARM):
     agent._engine.set_stats(losses[i % 5]); agent.update_from_replay(replay, B)
