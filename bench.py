@@ -29,6 +29,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E
 S, A, H, L, B = 60, 2, 1024, 2, 1024
 
 
@@ -517,6 +518,16 @@ def main():
                                           "every launch (~2.5 us of event overhead inside each figure)" % psteps,
                         # every launch of one update, HIP-event timed on the launch stream (instrumented pass)
                         step_launches_us={p["name"]: round(1e3 * p["total_ms"] / psteps, 2) for p in prof if p["launches"]})
+            # SURVEY.md §8(d) asks for both fractions: the HBM-bound launch of the update is the value group's
+            # Adam + Polyak sweep (36 B per parameter + the folded slab combines, algorithmic bytes from the launch site)
+            sweeps = [p for p in prof if p["launches"] and "adam_ema_kernel" in p["name"] and p["bytes"] > 0]
+            if sweeps:
+                sw = max(sweeps, key=lambda p: p["bytes"])
+                sw_ms = sw["total_ms"] / sw["launches"]
+                gbs = sw["bytes"] / sw["launches"] / (sw_ms * 1e-3) / 1e9
+                roof["hbm_bound_launch"] = dict(bound="hbm", launch=sw["name"], achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
+                                                frac=gbs / PEAK_HBM_GBS, avg_launch_us=sw_ms * 1e3,
+                                                bytes_per_launch=sw["bytes"] / sw["launches"])
 
     if rank == 0:
         steps_per_s = a.steps / elapsed

@@ -22,6 +22,7 @@ _PIPE_SYNC = __import__("os").environ.get("PORL_PIPE_SYNC", "signal")
 # H=256 B=256 9 470 -> 10 990; H=256 B=1024 8 160 -> 8 060; H=1024 B=1024 3 365 -> 3 315 — at GPU-bound sizes the
 # denser issue order shifts the two streams against each other and costs ~1 %).
 _PIPE_ONECALL = __import__("os").environ.get("PORL_PIPE_ONECALL", "auto")
+_DP_POLICY_GROUP = __import__("os").environ.get("PORL_DP_POLICY_GROUP", "1") != "0"
 _ONECALL_MAX_WORK = 32 << 20        # batch * hidden_dim^2 below which the update is host-bound
 
 class ArenaAdam:
@@ -290,10 +291,10 @@ class IqlAgentBase(nn.Module):
                     ev_f.record(side)
                 eng.policy_backward(hp)
                 if world > 1 and self._sharded():         # loss statistics stay per-rank shares in this mode
-                    self._sharded_apply(IqlEngine.GROUP_POL, hp, p_opt)
+                    self._sharded_apply(IqlEngine.GROUP_POL, hp, p_opt, self._exchange_for(IqlEngine.GROUP_POL, True))
                 else:
                     if world > 1:
-                        ex.allreduce_sum_(eng.grads_pol)
+                        self._exchange_for(IqlEngine.GROUP_POL, True).allreduce_sum_(eng.grads_pol)
                     eng.policy_apply(hp)
                 if _PIPE_SYNC == "signal" and use_sig:
                     eng.signal(eng.SIG_POLICY, seq, side)
@@ -317,12 +318,28 @@ class IqlAgentBase(nn.Module):
         eng, ex = self._engine, self._exchange
         return self.grad_exchange == "reduce_scatter" and ex.can_shard(eng.grads_vf) and ex.can_shard(eng.grads_pol)
 
-    def _sharded_apply(self, group, hp, opt):
+    def _exchange_for(self, group, pipelined):
+        """The exchange object a phase's collectives go through.  torch.distributed runs all collectives of ONE process
+        group (one RCCL communicator) on one internal stream in issue order, so with a single group the policy
+        exchange of update t (issued on the side stream, ready only when that phase's backward is done) would sit in
+        front of the value exchange of update t+1 and serialise the two streams again.  In pipelined mode the policy
+        group therefore gets a process group of its own (same ranks: `dist.new_group()`, created on first use by every
+        rank at the same point of the program); PORL_DP_POLICY_GROUP=0 keeps the single group."""
+        ex = self._exchange
+        if group != IqlEngine.GROUP_POL or not pipelined or ex.world_size == 1 or not _DP_POLICY_GROUP:
+            return ex
+        if getattr(self, "_exchange_pol", None) is None:
+            import torch.distributed as dist
+            self._exchange_pol = GradExchange(dist.new_group())
+        return self._exchange_pol
+
+    def _sharded_apply(self, group, hp, opt, ex=None):
         """reduce-scatter(SUM) of the group's gradients, torch-exact Adam on this rank's slice only,
         all-gather of the updated parameters; the target network is then swept locally (Polyak) from the gathered
         parameters.  Moments of the other slices are not kept here: ArenaAdam.state_dict() gathers them."""
         from .. import engine as E
-        eng, ex = self._engine, self._exchange
+        eng = self._engine
+        ex = ex or self._exchange
         p, g, m, v, tgt = eng.group(group)
         gs = self._gslice.get(group)
         if gs is None or gs.numel() != p.numel() // ex.world_size:

@@ -5,7 +5,8 @@ import collections, csv, json, os, sqlite3, subprocess, sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(REPO, "gpurun_out", "r02", "prof")
-OUT = os.path.join(REPO, "profiles")
+OUT = os.environ.get("PORL_PROFILES_OUT", os.path.join(REPO, "profiles"))    # on the GPU box: a directory under gpurun_out/
+os.makedirs(OUT, exist_ok=True)
 sys.path.insert(0, os.path.join(REPO, "scripts"))
 from rocpd_pmc_table import table
 
