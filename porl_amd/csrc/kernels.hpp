@@ -619,7 +619,7 @@ struct HeadBwdArgs {
   int B, H, ld, parts;
   float tau, discount, inv_batch;
 };
-constexpr int HEAD_ROWS = 16;            // rows per block; all 16 row loads of a thread are in flight together
+constexpr int HEAD_ROWS = 8;             // rows per block (all row loads of a thread in flight together); a wave walks HEAD_ROWS/4 rows of the head in turn, so 8 instead of 16 halves that dependent chain and fills all 256 CUs at B = 1024
 
 __global__ __launch_bounds__(256) void relu_head_bwd_kernel(const HeadBwdArgs a) {
   __shared__ float sh_dv[2][HEAD_ROWS];
