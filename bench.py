@@ -328,6 +328,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows-per-gpu", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--hidden", type=int, default=0,
+                    help="por: hidden width other than the headline's 1024 (e.g. 256, the reference's class default, "
+                         "value_functions.py:32); with --batch for the small-network figures of DESIGN.md §7")
     ap.add_argument("--angle-bins", type=int, default=360, help="sorl_enc: costmap rows (360 = the reference's image)")
     ap.add_argument("--dist-bins", type=int, default=256, help="sorl_enc: costmap columns")
     ap.add_argument("--enc-dtype", default="fp32", choices=["fp32", "bf16"],
@@ -341,6 +344,11 @@ def main():
         return bench_cql(a)
     if a.workload == "sorl_enc":
         return bench_sorl_enc(a)
+    global H, B
+    if a.hidden:
+        H = a.hidden                        # not the headline configuration: config.workload says so
+    if a.batch:
+        B = a.batch
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(a.gpus)          # bare `python bench.py --gpus N`: this process never touches a GPU
 
@@ -536,7 +544,7 @@ def main():
         # (its gradient is the mean over the world*1024 rows).  At N=1 the two numbers coincide.
         units_per_s = steps_per_s * world
         out = {
-            "metric": "gradient-steps/sec (POR update, batch=1024)",
+            "metric": "gradient-steps/sec (POR update, batch=%d)" % B,
             "value": units_per_s, "unit": "gradient-steps/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
