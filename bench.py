@@ -155,6 +155,10 @@ def bench_cql(a):
         ach = alg_bytes / (avg_us * 1e-6) / 1e9
         roof = dict(bound="hbm", kernel=dom[0]["name"], achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0,
                     traffic=None, avg_launch_us=avg_us, launches=dom[0]["launches"], algorithmic_bytes_per_launch=alg_bytes,
+                    # the other roof (138 368 MAC per sample = 3 forward + 2 backward passes of the
+                    # 20 864-MAC network): neither binds — the step is a chain of dependent 32-row layer stages
+                    mfma_tflops=2.0 * 138368 * Bq / (avg_us * 1e-6) / 1e12 if (Sq, Aq) == (60, 10) else None,
+                    mfma_frac=(2.0 * 138368 * Bq / (avg_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if (Sq, Aq) == (60, 10) else None,
                     note="latency-bound: 2.6 MB of compulsory traffic per step, one block per 32 rows walks every layer",
                     all_kernels_us_per_step={p["name"]: 1e3 * p["total_ms"] / a.steps for p in prof if p["launches"]})
     # CPU baseline: eager PyTorch-CPU restatement (oracle/torch_cpu.py: autograd + torch.optim.Adam, like the reference

@@ -58,6 +58,35 @@ if os.environ.get("SPINMODE") in ("two", "twosmall"):
             E.gemm_f32(0, sa, sb, M, 1024, 1024, 1024, 1024, sc2, 1024, tile=3)
             E.adam_ema(bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], 1e-4, it + 1, ema_beta=0.005)
     torch.cuda.synchronize()
+if os.environ.get("SPINMODE") in ("sigpp", "sigload"):
+    # signal ping-pong between two streams (the pipelined update's ordering mechanism) with tiny kernels, or with the
+    # update-sized GEMMs / sweeps in between ("sigload")
+    import ctypes as C
+    from porl_amd import _native as N
+    lib = N.lib()
+    sA, sB = C.c_void_p(), C.c_void_p()
+    N.check(lib.porl_signal_create(C.byref(sA)), "sig"); N.check(lib.porl_signal_create(C.byref(sB)), "sig")
+    load = os.environ["SPINMODE"] == "sigload"
+    sa, sb = torch.randn(4096, 1024, device=dev), torch.randn(1024, 1024, device=dev)
+    sc, sc2 = torch.empty(4096, 1024, device=dev), torch.empty(4096, 1024, device=dev)
+    bufs = [torch.zeros(2_200_000 if load else 4096, device=dev) for _ in range(5)]
+    side = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    for it in range(1, int(os.environ.get("SPINIT", "100")) + 1):
+        if load:
+            E.gemm_f32(0, sa, sb, 4096, 1024, 1024, 1024, 1024, sc, 1024, tile=3)
+        if it > 1:
+            N.check(lib.porl_signal_wait_ge(sB, it - 1, C.c_void_p(main.cuda_stream)), "wait")
+        E.adam_ema(bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], 1e-4, it, ema_beta=0.005)
+        N.check(lib.porl_signal_write(sA, it, C.c_void_p(main.cuda_stream)), "write")
+        with torch.cuda.stream(side):
+            N.check(lib.porl_signal_wait_ge(sA, it, C.c_void_p(side.cuda_stream)), "wait")
+            if load:
+                E.gemm_f32(0, sa, sb, 4096, 1024, 1024, 1024, 1024, sc2, 1024, tile=3)
+            N.check(lib.porl_signal_write(sB, it, C.c_void_p(side.cuda_stream)), "write")
+            if load:
+                E.gemm_f32(0, sa, sb, 2048, 1024, 1024, 1024, 1024, sc2, 1024, tile=3)
+    torch.cuda.synchronize()
 if os.environ.get("SPINMODE") == "agent":
     torch.manual_seed(1)
     scratch = POR(args, max_steps=1000, tau=0.9, alpha=10.0, device=dev)
