@@ -331,6 +331,12 @@ class IqlAgentBase(nn.Module):
         if getattr(self, "_exchange_pol", None) is None:
             import torch.distributed as dist
             self._exchange_pol = GradExchange(dist.new_group())
+            # build the new group's communicator now, with nothing else of this agent in flight behind it: one tiny
+            # collective and a device synchronisation (once per agent; every rank reaches this point in its first
+            # pipelined update)
+            probe = torch.zeros(1, dtype=torch.float32, device=self._engine.device)
+            dist.all_reduce(probe, group=self._exchange_pol.group)
+            torch.cuda.synchronize(self._engine.device)
         return self._exchange_pol
 
     def _sharded_apply(self, group, hp, opt, ex=None):
