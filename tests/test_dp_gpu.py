@@ -100,3 +100,27 @@ def test_bench_starts_its_own_ranks_from_the_bare_command():
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"] == "gloo"
     assert out["config"]["global_batch"] == 2048 and out["scaling"] == "weak"
     assert np.isfinite([out["value"], out["final_losses"]["v_loss"], out["final_losses"]["g_loss"]]).all()
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's N > 1 command: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` — ranks come from the launcher's environment.  Rehearsed with gloo, two ranks
+    on the box's one GPU."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PORL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+                        "--gpus", "2", "--steps", "4", "--warmup", "2", "--rows-per-gpu", "20000", "--no-roofline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["global_batch"] == 2048
+    assert np.isfinite([out["value"], out["final_losses"]["v_loss"], out["final_losses"]["g_loss"]]).all()
