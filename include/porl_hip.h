@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define PORL_ABI_VERSION 3
+#define PORL_ABI_VERSION 4
 #define PORL_MAX_HIDDEN 8
 
 #define PORL_OK 0

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libporl_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/porl_hip.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
