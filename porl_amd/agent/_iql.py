@@ -226,10 +226,16 @@ class IqlAgentBase(nn.Module):
             p_opt.step_count += 1
             hp = self._hyper(batch, v_opt, p_opt)
             vr = eng._values_read
-            eng.update_pipelined(hp, replay, batch, seq,
-                                 wait_policy_seq=max(0, seq - eng.SLOTS) if _PIPE_SYNC == "signal" else 0,
-                                 wait_fwd_seq=vr[1] if isinstance(vr, tuple) else 0,
-                                 write_policy=_PIPE_SYNC == "signal")
+            try:
+                eng.update_pipelined(hp, replay, batch, seq,
+                                     wait_policy_seq=max(0, seq - eng.SLOTS) if _PIPE_SYNC == "signal" else 0,
+                                     wait_fwd_seq=vr[1] if isinstance(vr, tuple) else 0,
+                                     write_policy=_PIPE_SYNC == "signal")
+            except Exception:          # rejected arguments (e.g. batch > max_batch): nothing was launched, undo the counters
+                eng._seq -= 1
+                v_opt.step_count -= 1
+                p_opt.step_count -= 1
+                raise
             replay.draws += 1
             eng._values_read, eng._policy_done = ("sig", seq), True
             sched.step()
