@@ -1440,6 +1440,12 @@ int porl_iql_update_pipelined(porl_iql* h, const porl_iql_hyper* hp, int32_t bat
   if (main_stream == side_stream) PORL_FAIL(PORL_ERR_INVALID, "the two phases need two streams");
   if (!(h->mode & PORL_IQL_MODE_TWO_SLOTS) || !(h->mode & PORL_IQL_MODE_FOLD_COMBINE))
     PORL_FAIL(PORL_ERR_INVALID, "pipelined updates need PORL_IQL_MODE_TWO_SLOTS | PORL_IQL_MODE_FOLD_COMBINE");
+  // reject bad minibatch arguments before anything is enqueued (porl_iql_load_batch_sampled checks them again)
+  if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
+  if (!rows || n_rows < batch || row_stride < 2 * (int64_t)h->cfg.obs_dim + 2 + act_dim)
+    PORL_FAIL(PORL_ERR_INVALID, "bad replay rows (need batch <= n_rows, row stride >= 2*S+2+A)");
+  if (target_is_action ? h->cfg.pol_out_dim != act_dim : h->cfg.pol_out_dim != h->cfg.obs_dim)
+    PORL_FAIL(PORL_ERR_INVALID, "policy target width mismatch");
   // the staging slot loaded next was last read by the policy phase PORL_IQL_SLOTS updates ago
   if (wait_policy_seq) PORL_TRY(porl_signal_wait_ge(sig_policy, wait_policy_seq, main_stream));
   PORL_TRY(porl_iql_load_batch_sampled(h, batch, rows, row_stride, n_rows, act_dim, target_is_action, seed, step, nullptr, main_stream));

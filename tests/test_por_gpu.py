@@ -516,3 +516,26 @@ def test_input_layer_kernel_is_bit_identical_to_the_grouped_gemm(S, H, B):
         assert torch.equal(x, y)
     for x, y in zip(out[0][2], out[1][2]):
         assert torch.equal(x, y)
+
+
+def test_one_call_pipelined_update_rejects_bad_arguments_without_side_effects():
+    """porl_iql_update_pipelined (the small-network fast path of update_from_replay) validates the minibatch before it
+    enqueues anything: an oversized batch raises, the step counters stay where they were, and the agent goes on to
+    produce the same results as one that never saw the bad call."""
+    from porl_amd import _native as N
+    from porl_amd.buffer.replay_buffer import PackedReplay
+    S, A, B, H = 60, 2, 64, 64
+    rows = make_rows(5_000, S, A, seed=9)
+    a, b = _make_por(S, H, 2, B), _make_por(S, H, 2, B)
+    for ag in (a, b):
+        ag.async_losses = True
+    ra, rb = PackedReplay(rows, S, A, DEV, seed=4), PackedReplay(rows, S, A, DEV, seed=4)
+    a.update_from_replay(ra, B)
+    b.update_from_replay(rb, B)
+    with pytest.raises(N.NativeError):
+        a.update_from_replay(ra, B + 1)                      # max_batch is B
+    assert a.v_optimizer.step_count == 1 and ra.draws == rb.draws
+    a.update_from_replay(ra, B)
+    b.update_from_replay(rb, B)
+    for (k, x), y in zip(a.state_dict().items(), b.state_dict().values()):
+        assert torch.equal(x, y), k
