@@ -68,7 +68,25 @@ class ArenaAdam:
             ex.all_gather_(m)
             ex.all_gather_(v)
 
+    def _unshard(self):
+        """Before a whole-group Adam on every rank (all_reduce exchange): moments of the other ranks' slices are stale
+        after reduce-scatter updates, so gather them once (collective: every rank takes the same branch because
+        `grad_exchange` is per-agent configuration, identical on all ranks)."""
+        if self.sharded:
+            self._gather_moments()
+            self.sharded = False
+
+    def consolidate_state(self):
+        """Data-parallel checkpointing: call on EVERY rank; afterwards `state_dict()` is purely local, so the usual
+        `if rank == 0: torch.save(opt.state_dict())` cannot deadlock.  The next sharded update marks the state as
+        sharded again."""
+        self._agent.flush()
+        self._unshard()
+
     def state_dict(self):
+        """torch.optim.Adam's format.  DATA-PARALLEL NOTE: after updates in the default `grad_exchange=
+        "reduce_scatter"` mode this call all-gathers the moments and is therefore a COLLECTIVE — every rank must make
+        it (or every rank calls `consolidate_state()` first and rank 0 alone calls `state_dict()`)."""
         self._agent.flush()
         self._gather_moments()
         ms, vs = self._moments()
@@ -92,6 +110,7 @@ class ArenaAdam:
         if len(steps) > 1:
             raise ValueError("per-parameter Adam step counts differ; the flat sweep needs one counter")
         self.step_count = steps.pop() if steps else 0
+        self.sharded = False               # every slice was just written on this rank (all ranks load the same file)
         g = sd["param_groups"][0]
         for k in ("lr", "betas", "eps", "initial_lr"):
             if k in g:
@@ -273,6 +292,7 @@ class IqlAgentBase(nn.Module):
             self._sharded_apply(IqlEngine.GROUP_VF, hp, v_opt)
         else:
             if world > 1:
+                v_opt._unshard()
                 ex.allreduce_sum_(eng.grads_vf)
             eng.wait_values_read()             # the PREVIOUS update's policy phase has read the old value nets
             eng.value_apply(hp)
@@ -300,6 +320,7 @@ class IqlAgentBase(nn.Module):
                     self._sharded_apply(IqlEngine.GROUP_POL, hp, p_opt, self._exchange_for(IqlEngine.GROUP_POL, True))
                 else:
                     if world > 1:
+                        p_opt._unshard()
                         self._exchange_for(IqlEngine.GROUP_POL, True).allreduce_sum_(eng.grads_pol)
                     eng.policy_apply(hp)
                 if _PIPE_SYNC == "signal" and use_sig:
@@ -314,6 +335,7 @@ class IqlAgentBase(nn.Module):
             if self._sharded():
                 self._sharded_apply(IqlEngine.GROUP_POL, hp, p_opt)
             else:
+                p_opt._unshard()
                 ex.allreduce_sum_(eng.grads_pol)
                 eng.policy_apply(hp)
             ex.allreduce_stats_(eng.stats)
@@ -390,7 +412,14 @@ class IqlAgentBase(nn.Module):
         v_opt.step_count += 1
         hp = self._hyper(B, v_opt, v_opt)
         eng.value_backward(hp)
+        if ex.world_size > 1 and self._sharded():
+            # same exchange as the full update: after a reduce-scatter update a rank holds current Adam moments for its
+            # own slice only, so a whole-group Adam here would use stale moments everywhere else
+            self._sharded_apply(IqlEngine.GROUP_VF, hp, v_opt)
+            ex.allreduce_stats_(eng.stats)
+            return
         if ex.world_size > 1:
+            v_opt._unshard()                   # (all_reduce mode after sharded updates: make every slice current first)
             ex.allreduce_sum_(eng.grads_vf)
             ex.allreduce_stats_(eng.stats)
         eng.value_apply(hp)

@@ -56,7 +56,15 @@ __global__ __launch_bounds__(256) void qr_loss_kernel(const QrLossArgs a) {
   float* T = sh_t[wave];
   for (int i = lane; i < N; i += 64) T[i] = r + a.gamma * zt[best * N + i] * nd;
   __builtin_amdgcn_wave_barrier();
-  const int at = (int)a.actions[b];
+  const int64_t at64 = a.actions[b];
+  if (at64 < 0 || at64 >= A) {
+    // an action outside [0, A): the reference's gather raises IndexError (qr_dqn_trainer.py:147).  No access is made with
+    // it here: the row contributes no gradient and a NaN loss term, which the host turns into that IndexError
+    for (int j = lane; j < a.ld; j += 64) dz[j] = 0.f;
+    if (lane == 0) a.row_loss[b] = __builtin_nanf("");
+    return;
+  }
+  const int at = (int)at64;
   for (int j = lane; j < a.ld; j += 64)                       // every element is written exactly once
     if (j < at * N || j >= at * N + N) dz[j] = 0.f;
   float loss = 0.f;
@@ -211,7 +219,13 @@ __global__ __launch_bounds__(256) void c51_loss_kernel(const C51LossArgs a) {
     }
   }
   __builtin_amdgcn_wave_barrier();
-  const int at = (int)a.actions[b];
+  const int64_t at64 = a.actions[b];
+  if (at64 < 0 || at64 >= A) {                                 // as in qr_loss_kernel: no access through a bad action index
+    for (int j = lane; j < a.ld; j += 64) dl[j] = 0.f;
+    if (lane == 0) a.row_loss[b] = __builtin_nanf("");
+    return;
+  }
+  const int at = (int)at64;
   float mx = -INFINITY;
   for (int n = lane; n < N; n += 64) mx = fmaxf(mx, lc[at * N + n]);
   mx = wmax(mx);

@@ -805,8 +805,9 @@ int porl_iql_value_backward(porl_iql* h, const porl_iql_hyper* hp, void* stream)
 // long ones as extra reduce+Adam blocks), the others (loss statistics) ride along as plain reduce blocks.
 static int adam_launch(float* p, float* g, float* m, float* v, float* tgt, int64_t n, double lr, int step,
                        double b1, double b2, double eps, double ema_beta, hipStream_t s, const ReduceArgs* fin = nullptr) {
-  if (n % 4) PORL_FAIL(PORL_ERR_INVALID, "adam range must be a multiple of 4 floats");
+  if (n < 0 || n % 4) PORL_FAIL(PORL_ERR_INVALID, "adam range must be a non-negative multiple of 4 floats");
   if (step < 1) PORL_FAIL(PORL_ERR_INVALID, "adam step must be >= 1");
+  if (n == 0 && !(fin && fin->njobs)) return PORL_OK;      // an empty range is an empty sweep (the grid maths below divide by it)
   AdamArgs a{};
   a.p = p; a.g = g; a.m = m; a.v = v; a.tgt = tgt;
   // torch._single_tensor_adam: python doubles, rounded to fp32 where they meet tensors
@@ -820,7 +821,7 @@ static int adam_launch(float* p, float* g, float* m, float* v, float* tgt, int64
   // one float4 per thread and a single trip through the block's loop whenever the grid allows it: a second, nearly
   // empty trip would double every block's memory round trips (measured: 12 -> 19 us on the 80 MB value group)
   const int sweep_blocks = (int)std::min<long>((a.n4 + 255) / 256, 1 << 20);
-  a.span4 = ((a.n4 + sweep_blocks - 1) / sweep_blocks + 255) / 256 * 256;
+  a.span4 = sweep_blocks ? ((a.n4 + sweep_blocks - 1) / sweep_blocks + 255) / 256 * 256 : 256;
   int reduce_blocks = 0;
   double extra_bytes = 0.0;
   if (fin) {
@@ -1434,7 +1435,7 @@ int porl_iql_update_pipelined(porl_iql* h, const porl_iql_hyper* hp, int32_t bat
                               int64_t n_rows, int32_t act_dim, int32_t target_is_action, uint64_t seed, uint64_t step,
                               void* sig_value, void* sig_fwd, void* sig_policy, uint64_t seq, uint64_t wait_policy_seq,
                               uint64_t wait_fwd_seq, int32_t write_policy, void* main_stream, void* side_stream) {
-  PORL_TRY(check_ready(h, false));
+  PORL_TRY(check_ready(h, false)); DevGuard _dg(h->device);
   if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
   if (!sig_value || !sig_fwd || !sig_policy || seq < 1) PORL_FAIL(PORL_ERR_INVALID, "three signal counters and seq >= 1 are required");
   if (main_stream == side_stream) PORL_FAIL(PORL_ERR_INVALID, "the two phases need two streams");
@@ -1442,8 +1443,9 @@ int porl_iql_update_pipelined(porl_iql* h, const porl_iql_hyper* hp, int32_t bat
     PORL_FAIL(PORL_ERR_INVALID, "pipelined updates need PORL_IQL_MODE_TWO_SLOTS | PORL_IQL_MODE_FOLD_COMBINE");
   // reject bad minibatch arguments before anything is enqueued (porl_iql_load_batch_sampled checks them again)
   if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
-  if (!rows || n_rows < batch || row_stride < 2 * (int64_t)h->cfg.obs_dim + 2 + act_dim)
-    PORL_FAIL(PORL_ERR_INVALID, "bad replay rows (need batch <= n_rows, row stride >= 2*S+2+A)");
+  if (!rows || n_rows < batch || n_rows > (int64_t(1) << 40) || act_dim < 0 ||
+      row_stride < 2 * (int64_t)h->cfg.obs_dim + 2 + act_dim)
+    PORL_FAIL(PORL_ERR_INVALID, "bad replay rows (need batch <= n_rows <= 2^40, row stride >= 2*S+2+A)");
   if (target_is_action ? h->cfg.pol_out_dim != act_dim : h->cfg.pol_out_dim != h->cfg.obs_dim)
     PORL_FAIL(PORL_ERR_INVALID, "policy target width mismatch");
   // the staging slot loaded next was last read by the policy phase PORL_IQL_SLOTS updates ago

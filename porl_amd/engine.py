@@ -160,10 +160,12 @@ class IqlEngine:
         device = _norm_device(device)
         if device == self.device:
             return self
-        self.join()
-        torch.cuda.synchronize(self.device)
-        self._free_signals()
+        if self.device.type == "cuda":                 # an engine still on the CPU has no streams, events or signals
+            self.join()
+            torch.cuda.synchronize(self.device)
+            self._free_signals()
         self._side, self._events = None, []
+        self._policy_done = self._values_read = None
         for name in ("params_vf", "params_tgt", "params_pol", "grads_vf", "grads_pol", "adam_m_vf",
                      "adam_v_vf", "adam_m_pol", "adam_v_pol", "stats"):
             setattr(self, name, getattr(self, name).to(device))

@@ -68,12 +68,20 @@ class DistTrainerBase:
         eng.apply(eng.hyper(self.gamma, 0.0, 1.0 / B, self.optimizer.step_count, g["lr"], g["betas"], g["eps"]))
         N.check(eng._lib.porl_reduce_mean(N.ptr(self._row_loss), B, N.ptr(self._loss), N.current_stream_ptr(eng.device)),
                 "porl_reduce_mean")
-        return self._loss if self.async_losses else float(self._loss)
+        if self.async_losses:
+            return self._loss
+        loss = float(self._loss)
+        if loss != loss and not bool(((self._actions >= 0) & (self._actions < self.action_size)).all()):
+            # the reference's `gather` raises on such a batch (qr_dqn_trainer.py:147, c51_trainer.py:155); the loss-head
+            # kernels make no access through a bad index — the row gets a NaN loss term and no gradient
+            raise IndexError("action index out of range in the minibatch (valid: 0..%d)" % (self.action_size - 1))
+        return loss
 
     def _load(self, batch):
         states, actions, rewards, next_states, dones = batch
         B = self._engine.load_batch(states, actions, rewards, next_states, dones)
-        return B, actions.long().contiguous(), rewards.float().contiguous(), dones.float().contiguous()
+        self._actions = actions = actions.long().contiguous()
+        return B, actions, rewards.float().contiguous(), dones.float().contiguous()
 
     def learn(self):
         return self.learn_on(*self.replay_buffer.sample(self.batch_size))

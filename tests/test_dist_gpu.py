@@ -106,3 +106,47 @@ def test_iqn_quantile_huber_loss_head_matches_reference_golden():
     N.check(N.lib().porl_reduce_mean(N.ptr(rl), B, N.ptr(out), N.current_stream_ptr(cur)), "porl_reduce_mean")
     np.testing.assert_allclose(float(out), float(z["loss"]), rtol=2e-6)
     np.testing.assert_allclose(dcur.cpu().numpy(), z["dcur"], atol=2e-8, rtol=2e-5)
+
+
+@pytest.mark.parametrize("head", ["qr", "c51"])
+def test_out_of_range_action_is_never_used_as_an_index(head):
+    """Round-2 advisor finding: an action outside [0, A) from replay must not become a device address.  The loss heads
+    give that row a NaN loss term and a zero gradient (and touch nothing outside the row); the trainers turn it into
+    the IndexError the reference's `gather` raises (qr_dqn_trainer.py:147, c51_trainer.py:155)."""
+    from porl_amd import _native as N
+    B, A, NQ = 9, 3, 8
+    g = torch.Generator().manual_seed(1)
+    guard = torch.full((B + 2, A * NQ), 7.0, device=DEV)           # one sentinel row before and after the gradient rows
+    dz = guard[1:B + 1]
+    zc, zo, zt = (torch.randn(B, A * NQ, generator=g).to(DEV) for _ in range(3))
+    act = torch.randint(0, A, (B,), generator=g)
+    act[2], act[5] = A, -1                                          # both sides of the valid range
+    act = act.to(DEV)
+    rew, done = torch.randn(B, generator=g).to(DEV), torch.zeros(B, device=DEV)
+    rl = torch.empty(B, device=DEV)
+    if head == "qr":
+        N.check(N.lib().porl_qr_loss(N.ptr(zc), N.ptr(zo), N.ptr(zt), A * NQ, N.ptr(act), N.ptr(rew), N.ptr(done), B, A, NQ,
+                                     0.99, 1.0, N.ptr(dz), N.ptr(rl), N.current_stream_ptr(zc)), "porl_qr_loss")
+    else:
+        sup = torch.linspace(-2, 2, NQ).to(DEV)
+        N.check(N.lib().porl_c51_loss(N.ptr(zc), N.ptr(zt), A * NQ, N.ptr(act), N.ptr(rew), N.ptr(done), N.ptr(sup), B, A, NQ,
+                                      0.99, -2.0, 2.0, N.ptr(dz), N.ptr(rl), N.current_stream_ptr(zc)), "porl_c51_loss")
+    rl, d = rl.cpu().numpy(), dz.cpu().numpy()
+    assert np.isnan(rl[[2, 5]]).all() and np.isfinite(np.delete(rl, [2, 5])).all()
+    assert not d[[2, 5]].any() and np.isfinite(d).all()
+    assert (guard[0] == 7.0).all() and (guard[B + 1] == 7.0).all()
+
+
+def test_trainer_raises_index_error_on_out_of_range_action():
+    from porl_amd.train.qr_dqn_trainer import QRDQNTrainer
+    S, A = 6, 3
+    torch.manual_seed(0)
+    t = QRDQNTrainer(S, A, 0.99, device=DEV, network_hidden_sizes=[32, 32], num_quantiles=8, batch_size=16)
+    g = torch.Generator().manual_seed(0)
+    st, ns = torch.randn(16, S, generator=g).to(DEV), torch.randn(16, S, generator=g).to(DEV)
+    ac = torch.randint(0, A, (16,), generator=g)
+    rw, dn = torch.randn(16, generator=g).to(DEV), torch.zeros(16, device=DEV)
+    assert np.isfinite(t.learn_on(st, ac.to(DEV), rw, ns, dn))
+    ac[3] = A + 4
+    with pytest.raises(IndexError):
+        t.learn_on(st, ac.to(DEV), rw, ns, dn)

@@ -124,3 +124,77 @@ def test_bench_under_torch_distributed_run():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["global_batch"] == 2048
     assert np.isfinite([out["value"], out["final_losses"]["v_loss"], out["final_losses"]["g_loss"]]).all()
+
+
+# ---- update -> vf_update in data-parallel mode (round-2 advisor finding: stale moments outside the rank's slice) --------
+def _sorl(B):
+    from types import SimpleNamespace
+    from porl_amd.agent.sorl import SORL
+    torch.manual_seed(0)
+    return SORL(SimpleNamespace(state_size=S, hidden_dim=H, n_hidden=L, layer_norm=False, action_size=2, max_batch=B),
+                1000, 0.9, 3.0, device=torch.device("cuda"))
+
+
+def _sorl_sequence(agent, rows, world, rank, per_rank):
+    """update, vf_update, update, vf_update on successive global minibatches; `per_rank` picks this rank's share."""
+    from porl_amd.util.synth import split_rows
+    out = []
+    for k in range(4):
+        glob = rows[k * world * BL:(k + 1) * world * BL]
+        local = glob[rank * BL:(rank + 1) * BL] if per_rank else glob
+        s, r, sp, d, a = split_rows(local, S, 2)
+        out.append(agent.update(s, a, r, sp, d)[0] if k % 2 == 0 else agent.vf_update(s, a, r, sp, d))
+    return out
+
+
+def _vf_worker(rank, world, port, out_dir, exchange, switch):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    agent = _sorl(BL)
+    agent.grad_exchange = exchange
+    rows = torch.from_numpy(_rows_n(4)).cuda()
+    losses = _sorl_sequence(agent, rows, world, rank, True)
+    if switch:                                               # change of exchange mode mid-run: moments must be gathered first
+        agent.grad_exchange = "all_reduce"
+        losses += _sorl_sequence(agent, rows, world, rank, True)
+    agent.v_optimizer.consolidate_state()                    # every rank; afterwards state_dict() is local
+    agent.policy_optimizer.consolidate_state()
+    sd = {k: v.cpu().numpy() for k, v in agent.state_dict().items()}
+    np.savez(os.path.join(out_dir, f"vf{rank}.npz"), losses=np.array(losses), **sd)
+    if rank == 0:                                            # rank 0 ALONE: must not be a collective any more
+        osd = agent.v_optimizer.state_dict()
+        np.savez(os.path.join(out_dir, "vfopt.npz"), m0=osd["state"][0]["exp_avg"].cpu().numpy(),
+                 v3=osd["state"][3]["exp_avg_sq"].cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _rows_n(n):
+    from porl_amd.util.synth import make_rows
+    return make_rows(2 * n * BL, S, 2, seed=33)
+
+
+@pytest.mark.parametrize("exchange,switch", [("reduce_scatter", False), ("all_reduce", False), ("reduce_scatter", True)])
+def test_update_then_vf_update_two_ranks_equals_single_process(tmp_path, exchange, switch):
+    """SORL.update followed by SORL.vf_update (sorl.py:130-152) with sharded optimizer state: every rank must apply Adam
+    with CURRENT moments, the ranks must stay replicas, and the result must equal the one-process run on the
+    concatenated minibatches."""
+    world = 2
+    mp.spawn(_vf_worker, args=(world, _free_port(), str(tmp_path), exchange, switch), nprocs=world, join=True)
+    g0, g1 = np.load(tmp_path / "vf0.npz"), np.load(tmp_path / "vf1.npz")
+    agent = _sorl(world * BL)
+    rows = torch.from_numpy(_rows_n(4)).cuda()
+    want = _sorl_sequence(agent, rows, world, 0, False)
+    if switch:
+        want += _sorl_sequence(agent, rows, world, 0, False)
+    np.testing.assert_allclose(g0["losses"], want, rtol=3e-6)
+    for k, v in agent.state_dict().items():
+        assert np.array_equal(g0[k], g1[k]), f"ranks diverged: {k}"
+        np.testing.assert_allclose(g0[k], v.cpu().numpy(), atol=2e-6, err_msg=k)
+    osd = agent.v_optimizer.state_dict()
+    opt = np.load(tmp_path / "vfopt.npz")
+    np.testing.assert_allclose(opt["m0"], osd["state"][0]["exp_avg"].cpu().numpy(), atol=1e-7, rtol=1e-4)
+    np.testing.assert_allclose(opt["v3"], osd["state"][3]["exp_avg_sq"].cpu().numpy(), atol=1e-10, rtol=1e-4)

@@ -539,3 +539,46 @@ def test_one_call_pipelined_update_rejects_bad_arguments_without_side_effects():
     b.update_from_replay(rb, B)
     for (k, x), y in zip(a.state_dict().items(), b.state_dict().values()):
         assert torch.equal(x, y), k
+
+
+def test_agent_built_on_the_cpu_moves_to_the_device_and_updates():
+    """Round-2 advisor finding: POR/SORL default to device=cpu like the reference (por.py:21, por_train.py:57 then moves
+    nothing — but `.to('cuda')` / `.cuda()` / load_state_dict-on-cpu-then-move are the usual patterns).  The moved agent
+    must equal an agent built on the device from the same seed."""
+    from porl_amd.agent.por import POR
+    S, H, B = 60, 64, 32
+    torch.manual_seed(0)
+    a = POR(_args(S, H, 2, B=B), 1000, 0.9, 10.0)                 # device=cpu default
+    assert a._engine.device.type == "cpu"
+    sd_cpu = {k: v.clone() for k, v in a.state_dict().items()}
+    a = a.to("cuda")
+    assert a._engine.device.type == "cuda" and all(p.is_cuda for p in a.parameters())
+    b = _make_por(S, H, 2, B)
+    for k, v in b.state_dict().items():
+        assert torch.equal(v.cpu(), sd_cpu[k]), k
+    rows = torch.from_numpy(make_rows(2 * B, S, 2, seed=4)).to(DEV)
+    for k in range(2):
+        s, r, sp, d, _ = split_rows(rows[k * B:(k + 1) * B], S, 2)
+        assert a.por_residual_update(s, sp, r, d) == b.por_residual_update(s, sp, r, d)
+    for (k1, v1), v2 in zip(a.state_dict().items(), b.state_dict().values()):
+        assert torch.equal(v1, v2), k1
+    # and back: a CPU copy holds the same numbers and refuses to compute (no CPU path)
+    c = a.cpu()
+    assert c._engine.device.type == "cpu"
+    for (k1, v1), v2 in zip(c.state_dict().items(), b.state_dict().values()):
+        assert v1.device.type == "cpu" and torch.equal(v1, v2.cpu()), k1
+    with pytest.raises(Exception):
+        c.por_residual_update(*[t.cpu() for t in split_rows(rows[:B], S, 2)[:1]] * 2, rows[:B, 0].cpu(), rows[:B, 0].cpu())
+    c = c.cuda()
+    s, r, sp, d, _ = split_rows(rows[:B], S, 2)
+    assert c.por_residual_update(s, sp, r, d) == b.por_residual_update(s, sp, r, d)
+
+
+def test_adam_sweep_over_an_empty_range_is_a_no_op():
+    """porl_adam_ema(n = 0) is a public ABI entry: an empty sweep, not a division by zero (round-2 advisor finding)."""
+    from porl_amd import _native as N
+    buf = torch.full((4, 4), 3.0, device=DEV)                     # valid, aligned pointers; length 0 (torch hands out a
+    p, g, m, v = (N.ptr(buf[i]) for i in range(4))                # null data_ptr for empty tensors, so go through the ABI)
+    N.check(N.lib().porl_adam_ema(p, g, m, v, None, 0, 1e-3, 1, 0.9, 0.999, 1e-8, 0.0, N.current_stream_ptr(buf)), "porl_adam_ema")
+    torch.cuda.synchronize()
+    assert (buf == 3.0).all()
