@@ -9,13 +9,25 @@ One "step" = one full POR update (agent/por.py:73-112 of the reference) INCLUDIN
 acquisition: draw B distinct rows of the device-resident replay shard, gather them, run value step +
 EMA + policy step.  Workload at N=1 is BASELINE config 2 (S=60, A=2, H=1024, L=2, B=1024, 1 M-row
 buffer, fp32); at N>1 every rank keeps its own 1.25 M-row shard (N=8 -> the 10 M-row buffer of config 4)
-and draws B=1024 local rows — weak scaling, gradients all-reduced with RCCL.
+and draws B=1024 local rows — weak scaling, gradients exchanged with RCCL.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : dominant kernel (the 128x128 fp32-MFMA grouped GEMM) timed with HIP events on its
-                 launch stream in a second, instrumented pass over the same K steps
-  cpu_baseline : the numpy oracle (oracle/por_oracle.py, BLAS threads stated) timed on the host cores
-                 on a bounded sample of the same workload (rank 0, N=1 only)
+  roofline     : dominant launch (the 4-net hidden-layer fp32-MFMA grouped GEMM) timed with HIP events on its
+                 launch stream in a second, instrumented pass
+  cpu_baseline : eager PyTorch-CPU / the numpy oracle (oracle/) timed on the host cores on a bounded sample of the
+                 same workload (rank 0, N=1 only)
+  secondary    : (N=1) BASELINE configs 3 and 5, POR at the class-default width and the headline in the reference's
+                 synchronous calling convention — each its own short timed loop, none of them `value`
+  dp           : (N>1) which data-parallel modes ran, which one `value` is from, what failed
+
+N > 1.  Every GPU process is the CHILD of a supervisor that makes no GPU call: under
+torch.distributed.run each launched rank supervises its own child, for the bare `python bench.py --gpus N` one
+parent starts and supervises all N.  The child times the data-parallel modes from the most conservative to the
+most aggressive — SUM all-reduce on one stream; reduce-scatter -> sharded Adam -> all-gather on one stream; the same
+pipelined over two streams with one RCCL communicator; with a communicator of its own for the policy group — and
+reports after each.  A mode that dies or hangs (process-group timeout, supervisor deadline: the exact child PIDs are
+killed) costs only itself: the line is built from the modes that finished, `value` = the best of them, and
+`dp.failed` names the rest.  No rank is ever re-executed in place.
 """
 from __future__ import annotations
 
@@ -29,19 +41,26 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E
 S, A, H, L, B = 60, 2, 1024, 2, 1024
 
+DP_MODES = ("allreduce_1stream", "reduce_scatter_1stream", "reduce_scatter_pipelined_1comm", "reduce_scatter_pipelined_2comm")
 
-def por_flops_per_sample():
-    """14 440 448 MAC per sample."""
-    mac_v = S * H + H * H + H
-    mac_p = S * H + H * H + H * S
+
+def por_flops_per_sample(h=None):
+    """14 440 448 MAC per sample at H=1024."""
+    h = h or H
+    mac_v = S * h + h * h + h
+    mac_p = S * h + h * h + h * S
     fwd = 6 * mac_v + mac_p
-    bwd = 2 * (mac_v + H * H + H) + (mac_p + H * H + H * S)
+    bwd = 2 * (mac_v + h * h + h) + (mac_p + h * h + h * S)
     return 2 * (fwd + bwd)
 
 
+# =====================================================================================================================
+# CPU baselines (rank 0, N=1 only).  oracle/ is test infrastructure: it is imported HERE and nowhere in the timed GPU path.
+# =====================================================================================================================
 def cpu_baseline(budget_s=12.0):
     """CPU steps/s on the host, same shapes, bounded by wall time: the stronger of (a) eager PyTorch-CPU (MKL,
     autograd, torch.optim.Adam — how the reference itself runs; oracle/torch_cpu.py) and (b) the numpy oracle
@@ -111,15 +130,19 @@ def cpu_baseline(budget_s=12.0):
                        f"{other['value']:.1f} steps/s")
 
 
-def bench_cql(a):
-    """Secondary workload (BASELINE config 3): CQL(H) learn() at B=4096, S=60, A=10, Q-net 64-128-64, 100 k-row
-    buffer resident on the device, indices drawn on the device.  Not the headline metric."""
+# =====================================================================================================================
+# Secondary workloads: BASELINE configs 3 (CQL) and 5 (SORL + costmap encoder).  `--workload cql|sorl_enc` prints their
+# own line; the default run folds a short form of each into `secondary`.
+# =====================================================================================================================
+def measure_cql(steps, warmup, with_cpu=True):
+    """BASELINE config 3: CQL(H) learn() at B=4096, S=60, A=10, Q-net 64-128-64, 100 k-row buffer resident on the
+    device, rows drawn by the step kernel itself."""
     import numpy as np
     import torch
     from porl_amd.train.cql_trainer import CQLTrainer
     from porl_amd.util.synth import make_discrete_transitions
-    from oracle.por_oracle import CqlOracle
-    dev = torch.device("cuda", 0)
+    from porl_amd import engine as E
+    dev = torch.device("cuda", torch.cuda.current_device())
     Sq, Aq, Bq, Nq = 60, 10, 4096, 100_000
     torch.manual_seed(0)
     t = CQLTrainer(state_size=Sq, action_size=Aq, gamma=0.99, device=dev, batch_size=Bq)
@@ -128,96 +151,100 @@ def bench_cql(a):
     rb.states[:Nq], rb.actions[:Nq], rb.rewards[:Nq], rb.next_states[:Nq], rb.dones[:Nq] = st, ac, rw, ns, dn
     rb.size, rb.position = Nq, 0
     t.async_losses = True
-    for i in range(a.warmup):
+    for i in range(warmup):
         t.learn_device_sampled()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.steps):
+    for i in range(steps):
         t.learn_device_sampled()
         if i % 10 == 0:
             t.sync_target()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if not np.isfinite(t._engine.stats[:3].cpu().numpy()).all():
+        raise RuntimeError("non-finite CQL loss")
     # instrumented second pass: HIP events around the step kernel on its launch stream
-    from porl_amd import engine as E
+    psteps = max(steps, 50)
     E.prof_enable(True)
-    for i in range(a.steps):
+    for i in range(psteps):
         t.learn_device_sampled()
     prof = E.prof_read()
     E.prof_enable(False)
     roof = None
-    dom = [p for p in prof if p["name"] in ("qnet_fused_kernel", "qnet_resident_kernel") and p["launches"]]
+    dom = [p for p in prof if p["name"].startswith(("qnet_fused", "qnet_resident")) and p["launches"]]
     if dom:
+        d0 = max(dom, key=lambda p: p["total_ms"])
         # the step is HBM/latency-bound; algorithmic bytes = gathered rows + parameters/Adam state
         n_par = sum(p.numel() for p in t.q_network.parameters())
         alg_bytes = Bq * (2 * Sq + 3) * 4 + Bq * 8 + n_par * 28
-        avg_us = 1e3 * dom[0]["total_ms"] / dom[0]["launches"]
+        avg_us = 1e3 * d0["total_ms"] / d0["launches"]
         ach = alg_bytes / (avg_us * 1e-6) / 1e9
-        roof = dict(bound="hbm", kernel=dom[0]["name"], achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0,
-                    traffic=None, avg_launch_us=avg_us, launches=dom[0]["launches"], algorithmic_bytes_per_launch=alg_bytes,
+        tf = 2.0 * 138368 * Bq / (avg_us * 1e-6) / 1e12
+        roof = dict(bound="hbm", kernel=d0["name"], achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                    traffic=_committed_traffic("r03_counters_cql.json", d0["name"]) or _committed_traffic("r02_counters_cql.json", d0["name"]),
+                    avg_launch_us=avg_us, launches=d0["launches"], algorithmic_bytes_per_launch=alg_bytes,
                     # the other roof (138 368 MAC per sample = 3 forward + 2 backward passes of the
-                    # 20 864-MAC network): neither binds — the step is a chain of dependent 32-row layer stages
-                    mfma_tflops=2.0 * 138368 * Bq / (avg_us * 1e-6) / 1e12 if (Sq, Aq) == (60, 10) else None,
-                    mfma_frac=(2.0 * 138368 * Bq / (avg_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if (Sq, Aq) == (60, 10) else None,
-                    note="latency-bound: 2.6 MB of compulsory traffic per step, one block per 32 rows walks every layer",
-                    all_kernels_us_per_step={p["name"]: 1e3 * p["total_ms"] / a.steps for p in prof if p["launches"]})
-    # CPU baseline: eager PyTorch-CPU restatement (oracle/torch_cpu.py: autograd + torch.optim.Adam, like the reference
-    # runs) incl. numpy's O(N) sampling as buffer/replay_buffer.py:64 does it, threads tuned; the numpy oracle beside it
-    from oracle.torch_cpu import CqlTorchCpu
-    qsd = {k: v.detach().cpu().numpy() for k, v in t.q_network.state_dict().items()}
-    rng = np.random.default_rng(0)
-    tst, tac, trw, tns, tdn = (torch.from_numpy(x) for x in (st, ac, rw, ns, dn))
-
-    def torch_rate(budget, threads):
-        torch.set_num_threads(threads)
-        m = CqlTorchCpu(qsd, Aq)
-        n, c0 = 0, time.perf_counter()
-        while time.perf_counter() - c0 < budget:
-            idx = torch.from_numpy(rng.choice(Nq, Bq, replace=False))
-            m.learn(tst[idx], tac[idx], trw[idx], tns[idx], tdn[idx])
-            n += 1
-        return n / (time.perf_counter() - c0), n
-
-    ncpu = os.cpu_count() or 1
-    best_tt = max(sorted({x for x in (1, 4, 8, 16, 32) if x <= ncpu}), key=lambda x: torch_rate(0.5, x)[0])
-    cpu, n = torch_rate(4.0, best_tt)
-    o = CqlOracle(qsd, Aq)
-    n2, c0 = 0, time.perf_counter()
-    while time.perf_counter() - c0 < 2.0:
-        idx = rng.choice(Nq, Bq, replace=False)
-        o.learn(st[idx], ac[idx], rw[idx], ns[idx], dn[idx])
-        n2 += 1
-    cpu_np = n2 / (time.perf_counter() - c0)
-    out = {"metric": "gradient-steps/sec (CQL learn, batch=4096)", "value": a.steps / el,
-           "unit": "gradient-steps/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
-           "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    # 20 864-MAC network)
+                    mfma_tflops=tf, mfma_frac=tf / PEAK_FP32_MFMA_TFLOPS,
+                    all_kernels_us_per_step={p["name"]: round(1e3 * p["total_ms"] / psteps, 2) for p in prof if p["launches"]})
+    out = {"metric": "gradient-steps/sec (CQL learn, batch=4096)", "value": steps / el,
+           "unit": "gradient-steps/sec", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * el / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "CQL S=60 A=10 B=4096 Q-net 64-128-64, 100k-row device-resident buffer, indices drawn "
-                                  "and rows gathered on the device"},
-           "cpu_baseline": {"value": cpu, "unit": "gradient-steps/sec", "kind": "port", "cores": int(best_tt),
-                            "sample": f"{n} learn() steps of the eager PyTorch-CPU restatement (oracle/torch_cpu.py) incl. numpy "
-                                      f"sampling, {best_tt} threads (tuned) in 4 s; numpy oracle: {cpu_np:.1f} steps/s"}}
+                                  "and rows gathered on the device"}}
     if roof:
         out["roofline"] = roof
-    print(json.dumps(out), flush=True)
+    if with_cpu:
+        # CPU baseline: eager PyTorch-CPU restatement (oracle/torch_cpu.py: autograd + torch.optim.Adam, like the reference
+        # runs) incl. numpy's O(N) sampling as buffer/replay_buffer.py:64 does it, threads tuned; the numpy oracle beside it
+        from oracle.por_oracle import CqlOracle
+        from oracle.torch_cpu import CqlTorchCpu
+        qsd = {k: v.detach().cpu().numpy() for k, v in t.q_network.state_dict().items()}
+        rng = np.random.default_rng(0)
+        tst, tac, trw, tns, tdn = (torch.from_numpy(x) for x in (st, ac, rw, ns, dn))
+
+        def torch_rate(budget, threads):
+            torch.set_num_threads(threads)
+            m = CqlTorchCpu(qsd, Aq)
+            n, c0 = 0, time.perf_counter()
+            while time.perf_counter() - c0 < budget:
+                idx = torch.from_numpy(rng.choice(Nq, Bq, replace=False))
+                m.learn(tst[idx], tac[idx], trw[idx], tns[idx], tdn[idx])
+                n += 1
+            return n / (time.perf_counter() - c0), n
+
+        ncpu = os.cpu_count() or 1
+        best_tt = max(sorted({x for x in (1, 4, 8, 16, 32) if x <= ncpu}), key=lambda x: torch_rate(0.5, x)[0])
+        cpu, n = torch_rate(4.0, best_tt)
+        o = CqlOracle(qsd, Aq)
+        n2, c0 = 0, time.perf_counter()
+        while time.perf_counter() - c0 < 2.0:
+            idx = rng.choice(Nq, Bq, replace=False)
+            o.learn(st[idx], ac[idx], rw[idx], ns[idx], dn[idx])
+            n2 += 1
+        cpu_np = n2 / (time.perf_counter() - c0)
+        out["cpu_baseline"] = {"value": cpu, "unit": "gradient-steps/sec", "kind": "port", "cores": int(best_tt),
+                               "sample": f"{n} learn() steps of the eager PyTorch-CPU restatement (oracle/torch_cpu.py) incl. numpy "
+                                         f"sampling, {best_tt} threads (tuned) in 4 s; numpy oracle: {cpu_np:.1f} steps/s"}
+    return out
 
 
-def bench_sorl_enc(a):
-    """Secondary workload (BASELINE config 5): SORL.update with the FasterNet costmap encoder as backbone, B=512,
-    S=362 (360 beams + goal), feature_dim=256, H=512, fp32 (the parity bar is 1e-5, so no bf16).  One step =
-    encode s, encode s' (train-mode BatchNorm, DropPath), value + policy update.  Reports the per-kernel time
-    split of one step from an instrumented second pass."""
+def measure_sorl_enc(steps, warmup, batch=512, angle_bins=360, dist_bins=256, enc_dtype="fp32", with_cpu=True):
+    """BASELINE config 5: SORL.update with the FasterNet costmap encoder as backbone, S = angle_bins + 2 (beams + goal),
+    feature_dim=256, H=512.  One step = encode s, encode s' (train-mode BatchNorm, DropPath), value + policy update.
+    fp32 on the reference's 360x256 image is the parity configuration; 84x84 / bf16 are BASELINE's wording."""
     import numpy as np
     import torch
     from types import SimpleNamespace
     from porl_amd.agent.fasternet import FasterNet
     from porl_amd.agent.sorl import SORL
     from porl_amd import engine as E
-    dev = torch.device("cuda", 0)
-    Bq, F, Hq, Aq = a.batch or 512, 256, 512, 2
+    dev = torch.device("cuda", torch.cuda.current_device())
+    Bq, F, Hq, Aq = batch, 256, 512, 2
     torch.manual_seed(0)
-    n_ang, n_dist = a.angle_bins, a.dist_bins             # 360 x 256 = the reference's image; 84 x 84 = BASELINE's wording
-    backbone = FasterNet(3, F, max_batch=Bq, angle_bins=n_ang, dist_bins=n_dist, compute_dtype=a.enc_dtype)
+    n_ang, n_dist = angle_bins, dist_bins
+    backbone = FasterNet(3, F, max_batch=Bq, angle_bins=n_ang, dist_bins=n_dist, compute_dtype=enc_dtype)
     args = SimpleNamespace(state_size=n_ang + 2, feature_dim=F, hidden_dim=Hq, n_hidden=2, layer_norm=False, action_size=Aq,
                            max_batch=Bq)
     agent = SORL(args, max_steps=1000, tau=0.9, alpha=3.0, device=dev, backbone=backbone)
@@ -236,44 +263,48 @@ def bench_sorl_enc(a):
         k = i % nb
         agent.update(st[k, 0], act[k], rew[k], st[k, 1], done[k])
 
-    for i in range(a.warmup):
+    for i in range(warmup):
         one_step(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.steps):
+    for i in range(steps):
         one_step(i)
+    agent.flush()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     losses = agent._engine.stats[:2].cpu().numpy()
     if not np.isfinite(losses).all():
-        raise SystemExit("non-finite loss in the benchmark run")
+        raise RuntimeError("non-finite loss in the SORL + encoder run")
+    psteps = min(steps, 10)
     E.prof_enable(True)
-    for i in range(a.steps):
+    for i in range(psteps):
         one_step(i)
     prof = E.prof_read()
     E.prof_enable(False)
-    split = {p["name"]: p["total_ms"] / a.steps for p in prof if p["launches"]}
-    gemms = [p for p in prof if p["name"].startswith(("gemm_f32_kernel", "gemm_bf16_kernel")) and p["launches"]]
+    split = {p["name"]: round(p["total_ms"] / psteps, 4) for p in prof if p["launches"]}
+    gemms = [p for p in prof if p["name"].split(":")[-1].startswith(("gemm_f32_kernel", "gemm_bf16_kernel", "enc_")) and p["launches"]
+             and p["flops"] > 0]
     dom = max(gemms, key=lambda p: p["total_ms"])
     ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
     hbm = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9
     enc_flops = 2 * 2 * Bq * 0.86e9 * (n_ang * n_dist) / (360.0 * 256.0)
-    out = {"metric": "gradient-steps/sec (SORL update + FasterNet encoder, batch=512)", "value": a.steps / el,
-           "unit": "gradient-steps/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
-           "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32" if a.enc_dtype == "fp32" else "bf16 operands / f32 accumulate (encoder GEMMs), f32 elsewhere",
+    peak_tf = PEAK_FP32_MFMA_TFLOPS if enc_dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    roof = dict(kernel=dom["name"], launches=dom["launches"], avg_launch_us=1e3 * dom["total_ms"] / dom["launches"], traffic=None,
+                mfma_tflops=ach, mfma_frac=ach / peak_tf, hbm_gbs=hbm, hbm_frac=hbm / PEAK_HBM_GBS,
+                all_kernels_ms_per_step=split)
+    if enc_dtype == "fp32":
+        roof.update(bound="mfma", achieved=ach, peak=peak_tf, unit="TFLOP/s", frac=ach / peak_tf)
+    else:
+        roof.update(bound="hbm", achieved=hbm, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm / PEAK_HBM_GBS)
+    out = {"metric": "gradient-steps/sec (SORL update + FasterNet encoder, batch=%d)" % Bq, "value": steps / el,
+           "unit": "gradient-steps/sec", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * el / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if enc_dtype == "fp32" else "bf16 (encoder products and activations between them; f32 accumulate, f32 heads)",
            "data": "synthetic",
            "config": {"workload": f"SORL S={n_ang + 2} F={F} H={Hq} B={Bq} + FasterNet(3,{F}) encoder on {n_ang}x{n_dist} costmaps, "
                                   "2 encoder forwards (train-mode BN, DropPath) + value/policy update per step"},
-           "algorithmic_tflops": enc_flops * a.steps / el / 1e12,
-           "roofline": (dict(bound="mfma", kernel=dom["name"], achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                             frac=ach / PEAK_FP32_MFMA_TFLOPS) if a.enc_dtype == "fp32" else
-                        dict(bound="hbm", kernel=dom["name"], achieved=hbm, peak=8000.0, unit="GB/s", frac=hbm / 8000.0,
-                             algorithmic_bytes_note="rows x (K + N [+ N residual]) x 4 B per product: operands and "
-                                                    "results stay fp32 in HBM, only the multiply is bf16")) |
-                       dict(traffic=None, launches=dom["launches"],
-                            avg_launch_us=1e3 * dom["total_ms"] / dom["launches"], all_kernels_ms_per_step=split)}
-    if not a.no_cpu_baseline:
+           "algorithmic_tflops": enc_flops * steps / el / 1e12, "roofline": roof}
+    if with_cpu:
         sys.path.insert(0, os.path.join(REPO, "oracle"))
         import fasternet_oracle as FO
         sd = {k: v.cpu().numpy() for k, v in backbone.state_dict().items()}
@@ -287,43 +318,146 @@ def bench_sorl_enc(a):
         out["cpu_baseline"] = {"value": (bs / Bq) / dt, "unit": "gradient-steps/sec", "kind": "port", "cores": os.cpu_count(),
                                "sample": f"2 encoder forwards of oracle/fasternet_oracle.py (numpy fp32) on {bs} of the "
                                          f"{Bq} samples in {dt:.1f} s, scaled by {bs}/{Bq}; heads' update excluded (<1 %)"}
-    print(json.dumps(out), flush=True)
+    return out
 
 
-def spawn_ranks(n):
-    """`python bench.py --gpus N` without torchrun: start N rank processes (one GPU each) from a parent that makes
-    no HIP call at all — children are fresh interpreters (subprocess, no fork of GPU state, no re-exec) — relay
-    rank 0's JSON line and exit with the worst child code."""
+def _committed_traffic(fname, kernel):
+    """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/), or None."""
+    try:
+        tj = json.load(open(os.path.join(REPO, "profiles", fname)))
+        k = tj["kernels"]
+        for name, v in k.items():
+            if name == kernel or name.split("<")[0] == kernel.split("<")[0].split(":")[-1]:
+                return v.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def _brief(o, keys=("value", "ms_per_step", "steps", "warmup", "dtype")):
+    d = {k: o[k] for k in keys if k in o}
+    d["workload"] = o["config"]["workload"]
+    r = o.get("roofline")
+    if r:
+        d["dominant_kernel"] = {k: r[k] for k in ("kernel", "avg_launch_us", "bound", "frac", "mfma_frac", "hbm_frac", "traffic")
+                                if k in r and r[k] is not None}
+        if "hbm_frac" not in d["dominant_kernel"] and r.get("bound") == "hbm":
+            d["dominant_kernel"]["hbm_frac"] = r["frac"]
+    return d
+
+
+# =====================================================================================================================
+# Supervisor: a process that makes no GPU call, starts the rank process(es), follows their progress markers and builds
+# the line from whatever finished.
+# =====================================================================================================================
+def supervise(n_children, launched_by_torchrun):
     import socket
     import subprocess
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     import threading
-    out0 = []
-    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
+    setup_deadline = float(os.environ.get("PORL_BENCH_SETUP_DEADLINE_S", "330"))     # start -> first mode finished
+    mode_deadline = float(os.environ.get("PORL_BENCH_MODE_DEADLINE_S", "100"))       # between two progress markers
+    base_env = dict(os.environ, PORL_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONUNBUFFERED="1")
+    procs = []
+    if launched_by_torchrun:
+        my_rank = int(os.environ.get("RANK", "0"))
+        envs = [base_env]
+    else:
+        my_rank = 0
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        envs = [dict(base_env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_children), LOCAL_WORLD_SIZE=str(n_children),
+                     MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)) for r in range(n_children)]
+    for env in envs:
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE, text=True, bufsize=1))
+    state = dict(last=time.monotonic(), modes=[], final=None, markers=[0] * len(procs))
+    lock = threading.Lock()
+
+    def reader(i, p):
+        for ln in p.stdout:
+            ln = ln.rstrip("\n")
+            with lock:
+                if ln.startswith("PORL_MODE_DONE "):
+                    state["markers"][i] += 1
+                    state["last"] = time.monotonic()
+                elif ln.startswith("PORL_MODE "):
+                    state["modes"].append(json.loads(ln[len("PORL_MODE "):]))
+                elif ln.startswith("PORL_FINAL "):
+                    state["final"] = ln[len("PORL_FINAL "):]
+                    state["last"] = time.monotonic()
+                elif ln.strip():
+                    sys.stderr.write(f"[rank-child {i}] {ln}\n")
+
+    threads = [threading.Thread(target=reader, args=(i, p), daemon=True) for i, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    t_start = time.monotonic()
+    note = None
+
+    def kill_all(why):
+        nonlocal note
+        alive = [i for i, p in enumerate(procs) if p.poll() is None]
+        note = f"{why}; killed child processes {[procs[i].pid for i in alive]} (children {alive} were alive)"
+        sys.stderr.write("[bench supervisor] " + note + "\n")
+        for i in alive:
+            procs[i].kill()                                   # exactly the PIDs started above
+
     while any(p.poll() is None for p in procs):
-        if any(p.poll() not in (None, 0) for p in procs):    # a dead rank would leave the others in a collective
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()                                  # exactly the PIDs started above
         time.sleep(0.2)
-    reader.join(timeout=10)
+        now = time.monotonic()
+        with lock:
+            started = min(state["markers"]) > 0
+            idle = now - state["last"]
+            done = state["final"] is not None
+        bad = [i for i, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad:                                               # a dead rank leaves the others in a collective
+            time.sleep(3.0)                                   # (let them fail by themselves first: clearer messages)
+            kill_all(f"child {bad} exited with code {[procs[i].returncode for i in bad]}")
+            break
+        if done and idle > 30.0:
+            kill_all("result printed but the children did not exit within 30 s")
+            break
+        if not done and (idle > mode_deadline if started else now - t_start > setup_deadline):
+            kill_all(f"no progress marker for {idle:.0f} s" if started else f"no mode finished within {setup_deadline:.0f} s of start")
+            break
+    for p in procs:
+        try:
+            p.wait(timeout=15)
+        except Exception:
+            pass
+    for t in threads:
+        t.join(timeout=5)
     codes = [p.returncode for p in procs]
-    sys.stdout.write("".join(out0))
-    sys.stdout.flush()
-    if any(codes):
-        raise SystemExit(f"rank exit codes {codes}")
+    with lock:
+        final, modes, markers = state["final"], list(state["modes"]), list(state["markers"])
+    if my_rank != 0:
+        # under torchrun a non-zero exit of ANY worker tears the job down: this rank did its part if one mode finished
+        raise SystemExit(0 if markers and min(markers) > 0 else 1)
+    if final is not None:
+        out = json.loads(final)
+        if note:
+            out.setdefault("dp", {})["note"] = note
+    elif modes:
+        ok = [m for m in modes if m.get("ok")]
+        if not ok:
+            raise SystemExit(f"no data-parallel mode finished ({note}); rank exit codes {codes}")
+        out = dict(max(ok, key=lambda m: m["value"])["line"])
+        ran = {m["mode"] for m in modes}
+        wanted = [m for m in (os.environ.get("PORL_BENCH_MODES") or ",".join(DP_MODES)).split(",") if m]
+        out["dp"].update(modes=[{k: v for k, v in m.items() if k != "line"} for m in modes],
+                         failed=[m for m in wanted if m not in ran] + [m["mode"] for m in modes if not m.get("ok")],
+                         note=(note or "") + f"; rank exit codes {codes}; line built by the supervisor from the modes that finished")
+    else:
+        raise SystemExit(f"no result from the rank processes ({note}); exit codes {codes}")
+    print(json.dumps(out), flush=True)
+    raise SystemExit(0)
 
 
+# =====================================================================================================================
+# The GPU process
+# =====================================================================================================================
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="por", choices=["por", "cql", "sorl_enc"])
@@ -341,44 +475,65 @@ def main():
                     help="sorl_enc: operand type of the encoder's 1x1 / merge convolutions (fp32 = reference parity)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (configs 3 / 5, H=256, sync mode)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="issue every update back to back on one stream (profiling: kernels never overlap)")
     a = ap.parse_args()
     if a.workload == "cql":
-        return bench_cql(a)
+        print(json.dumps(measure_cql(a.steps, a.warmup, not a.no_cpu_baseline)), flush=True)
+        return
     if a.workload == "sorl_enc":
-        return bench_sorl_enc(a)
+        print(json.dumps(measure_sorl_enc(a.steps, a.warmup, a.batch or 512, a.angle_bins, a.dist_bins, a.enc_dtype,
+                                          not a.no_cpu_baseline)), flush=True)
+        return
     global H, B
     if a.hidden:
         H = a.hidden                        # not the headline configuration: config.workload says so
     if a.batch:
         B = a.batch
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return spawn_ranks(a.gpus)          # bare `python bench.py --gpus N`: this process never touches a GPU
+    force_dp = os.environ.get("PORL_BENCH_FORCE_DP") == "1"        # one rank, RCCL collectives really issued (tests)
+    if (a.gpus > 1 or force_dp) and os.environ.get("PORL_BENCH_CHILD") != "1":
+        # this process never touches a GPU: it starts the rank process(es) and follows them
+        return supervise(a.gpus, launched_by_torchrun="WORLD_SIZE" in os.environ and a.gpus > 1)
+    por_rank(a, force_dp)
 
+
+def por_rank(a, force_dp):
+    import datetime
     import numpy as np
     import torch
     import torch.distributed as dist
     from types import SimpleNamespace
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if a.gpus > 1 else 1
+    rank = int(os.environ.get("RANK", "0")) if a.gpus > 1 else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if a.gpus > 1 else 0
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dp = world > 1 or force_dp
     # PORL_BENCH_BACKEND=gloo rehearses the N>1 code path with several ranks on ONE GPU (no RCCL, no timing claim)
     backend = os.environ.get("PORL_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+            os.environ["PORL_DP_FORCE"] = "1"                  # parallel.GradExchange: active in a one-rank group
+        # a collective that does not complete within this time aborts the process (the supervisor then falls back on
+        # the modes that finished) instead of hanging until the driver's limit
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("PORL_BENCH_PG_TIMEOUT_S", "90")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
 
     from porl_amd.agent.por import POR
     from porl_amd.buffer.replay_buffer import PackedReplay
@@ -390,189 +545,309 @@ def main():
     shard = make_rows(rows_per_gpu, S, A, seed=1000 + rank)
     replay = PackedReplay(shard, S, A, dev, rank=0, world=1, seed=rank)
     del shard
-
-    args = SimpleNamespace(state_size=S, hidden_dim=H, n_hidden=L, layer_norm=False, action_size=A, max_batch=B)
-    torch.manual_seed(0)                                       # identical replicas on every rank
-    agent = POR(args, max_steps=1000, tau=0.9, alpha=10.0, device=dev)
-    agent.async_losses = True                                  # no host sync inside the loop
-    agent.pipeline = not a.no_pipeline
-    if os.environ.get("PORL_IQL_FOLD") == "0":                 # A/B: slab combines as separate launches
-        E.tune_set("iql_fold", 0)
-    if os.environ.get("PORL_L0_KERNEL") == "0":                # A/B: input layers through the grouped GEMM
-        E.tune_set("l0_kernel", 0)
-    for i, v in enumerate(os.environ.get("PORL_TILE_MAP", "").split(",")):      # A/B: e.g. "0,1,2,3" = round-1 choice
-        if v.strip():
-            E.tune_set("tile_map%d" % i, int(v))
-            E.tune_set("tile_map_short%d" % i, int(v))
-    if os.environ.get("PORL_IQL_PAD"):                         # A/B: "value,policy[,min_blocks]" LDS pads of the pipelined update
-        v = [int(x) for x in os.environ["PORL_IQL_PAD"].split(",")]
-        E.tune_set("iql_pad_value", v[0]); E.tune_set("iql_pad_policy", v[1])
-        if len(v) > 2:
-            E.tune_set("iql_pad_min_blocks", v[2])
-        if len(v) > 3:
-            E.tune_set("iql_pad_min_k", v[3])
-    if os.environ.get("PORL_GEMM_LDS_PAD"):                    # A/B: fewer co-resident GEMM blocks per CU (placement knob)
-        E.tune_set("gemm_lds_pad", int(os.environ["PORL_GEMM_LDS_PAD"]))
-    if os.environ.get("PORL_VBWD_TILE"):                       # A/B: tile of the value backward in pipelined mode
-        E.tune_set("vbwd_tile_short", int(os.environ["PORL_VBWD_TILE"]))
-    if os.environ.get("PORL_L0_TILE"):                         # A/B: tile of the K = 60 forward layers
-        E.tune_set("l0_tile", int(os.environ["PORL_L0_TILE"]))
-    losses = torch.zeros(a.steps + a.warmup, 8, device=dev)    # device-side loss history, one row per update
-
-    def one_step(i):
-        # draw B distinct rows of the resident shard + gather + split (one kernel), then the update;
-        # the three loss statistics of update i land in losses[i] without copies
-        agent._engine.set_stats(losses[i])
-        agent.update_from_replay(replay, B)
+    _apply_tuning_env(E)
 
     def barrier():
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
     # Set-up, not warm-up: ~50 ms of fp32-MFMA work on scratch tensors so that a short run (the driver times 20 steps
     # after 5 warm-up steps: 9 ms in all) does not measure the card's clock / power ramp from idle.  It touches no
     # agent state; the W warm-up updates and the K timed updates below are exactly as asked.  PORL_BENCH_SPINUP_MS=0
-    # turns it off.
+    # turns it off; the line states it as `setup_spinup_ms`.
     spin_ms = float(os.environ.get("PORL_BENCH_SPINUP_MS", "50"))
-    if spin_ms > 0:
-        sa, sb = torch.randn(4096, 1024, device=dev), torch.randn(1024, 1024, device=dev)
-        sc = torch.empty(4096, 1024, device=dev)
-        t_spin = time.perf_counter()
-        while (time.perf_counter() - t_spin) * 1e3 < spin_ms:
-            for _ in range(20):
-                E.gemm_f32(0, sa, sb, 4096, 1024, 1024, 1024, 1024, sc, 1024)
-            torch.cuda.synchronize()
-        del sa, sb, sc
 
-    for i in range(a.warmup):
-        one_step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        one_step(a.warmup + i)
-    agent.flush()                                              # a deferred policy step belongs to the timed work
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if world > 1:
-        # async mode keeps per-rank SHARES of the batch means in the history: one reduction after the timed
-        # loop makes them the global-batch statistics (sum of shares; minimum of the per-rank minima)
-        sums = losses[:, 0:2].contiguous()
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        losses[:, 0:2] = sums
-        mins = losses[:, 2].contiguous()
-        dist.all_reduce(mins, op=dist.ReduceOp.MIN)
-        losses[:, 2] = mins
-    lh = losses[:, :3].cpu().numpy()
-    if not np.isfinite(lh).all():
-        raise SystemExit("non-finite loss in the benchmark run")
+    def spinup():
+        if spin_ms > 0:
+            sa, sb = torch.randn(4096, 1024, device=dev), torch.randn(1024, 1024, device=dev)
+            sc = torch.empty(4096, 1024, device=dev)
+            t_spin = time.perf_counter()
+            while (time.perf_counter() - t_spin) * 1e3 < spin_ms:
+                for _ in range(20):
+                    E.gemm_f32(0, sa, sb, 4096, 1024, 1024, 1024, 1024, sc, 1024)
+                torch.cuda.synchronize()
 
-    # Not `value`: the same loop again for 1 000 updates.  After any idle the card needs ~10 ms of THIS workload to
-    # settle its clocks (scripts/bench_ramp.py: the first ~20 updates after a sync run 10 % slower, whatever GEMM or
-    # streaming spin-up precedes them), and a K = 20 run also pays the pipeline's fill and drain once; a training job
-    # runs millions of updates, so the sustained rate is reported beside the contract's K-step figure.
-    sustained = None
-    if world == 1 and a.steps < 1000 and os.environ.get("PORL_BENCH_SUSTAINED", "1") != "0":
-        n_s = 1000
+    def make_agent(mode):
+        args = SimpleNamespace(state_size=S, hidden_dim=H, n_hidden=L, layer_norm=False, action_size=A, max_batch=B)
+        torch.manual_seed(0)                                       # identical replicas on every rank
+        agent = POR(args, max_steps=1000, tau=0.9, alpha=10.0, device=dev)
+        agent.async_losses = mode != "sync"                        # "sync": the reference's convention (floats back, one host sync per update)
+        agent.pipeline = mode in ("pipelined", "reduce_scatter_pipelined_1comm", "reduce_scatter_pipelined_2comm")
+        agent.grad_exchange = "all_reduce" if mode == "allreduce_1stream" else "reduce_scatter"
+        agent.dp_policy_group = mode == "reduce_scatter_pipelined_2comm"
+        return agent
+
+    def timed_run(mode, steps, warmup, keep=False):
+        """W warm-up updates, then exactly K timed updates bracketed by barrier + device synchronisation; MAX over ranks."""
+        agent = make_agent(mode)
+        replay.draws = 0
+        losses = torch.zeros(steps + warmup, 8, device=dev)       # device-side loss history, one row per update
+
+        def one_step(i):
+            # draw B distinct rows of the resident shard + gather + split (one kernel), then the update;
+            # the three loss statistics of update i land in losses[i] without copies
+            agent._engine.set_stats(losses[i])
+            agent.update_from_replay(replay, B)
+
+        for i in range(warmup):
+            one_step(i)
         barrier()
-        ts = time.perf_counter()
-        for i in range(n_s):
-            one_step(a.warmup + i % a.steps)
-        agent.flush()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one_step(warmup + i)
+        agent.flush()                                              # a deferred policy step belongs to the timed work
         barrier()
-        sustained = n_s / (time.perf_counter() - ts)
+        elapsed = time.perf_counter() - t0
+        if dp:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            if agent.async_losses:
+                # async mode keeps per-rank SHARES of the batch means in the history: one reduction after the timed
+                # loop makes them the global-batch statistics (sum of shares; minimum of the per-rank minima)
+                sums = losses[:, 0:2].contiguous()
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+                losses[:, 0:2] = sums
+                mins = losses[:, 2].contiguous()
+                dist.all_reduce(mins, op=dist.ReduceOp.MIN)
+                losses[:, 2] = mins
+        lh = losses[:, :3].cpu().numpy()
+        if not np.isfinite(lh).all():
+            raise SystemExit(f"non-finite loss in the benchmark run (mode {mode})")
+        res = dict(mode=mode, elapsed=elapsed, steps_per_s=steps / elapsed, lh=lh, one_step=one_step, agent=agent)
+        if not keep:
+            res["agent"] = res["one_step"] = None
+            del agent
+        return res
 
-    roof = None
-    if not a.no_roofline:
-        # second pass, instrumented: HIP events around every kernel launch on the launch stream.  The timed loop above
-        # overlaps the policy phase with the next value phase on two streams; a kernel's roofline is quoted with the
-        # kernel ALONE on the chip, so this pass runs the same updates back to back on one stream.
-        agent.flush()
-        agent.pipeline = False
-        psteps = max(a.steps, 100)                 # enough launches for stable per-kernel averages whatever K is
-        E.prof_enable(True)
-        for i in range(psteps):
-            one_step(a.warmup + i % a.steps)
-        prof = E.prof_read()
-        E.prof_enable(False)
-        agent.pipeline = not a.no_pipeline
-        # profile labels are "<launch of the step>:<kernel>".  The roofline is quoted for the DOMINANT LAUNCH of the
-        # update (the labelled launch with the largest total time: the 4-net hidden-layer forward) — one kernel
-        # instantiation can serve launches of very different shapes, which a per-instantiation average would mix
-        gemms = [p for p in prof if p["launches"] and "gemm_f32_kernel" in p["name"]]
-        if gemms:
-            dom = max(gemms, key=lambda p: p["total_ms"])
-            name = dom["name"].split(":")[-1]
-            avg_ms = dom["total_ms"] / dom["launches"]
-            flops_per_launch = dom["flops"] / dom["launches"]
-            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            # HBM bytes per launch are NOT measured by this run: they come from the committed rocprofv3 --pmc passes
-            # over this same command (separate passes, as the microarch guide prescribes); the source file is named
-            traffic, traffic_src = None, None
-            for fname in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
-                try:
-                    tj = json.load(open(os.path.join(REPO, "profiles", fname)))
-                    traffic = tj["kernels"][name]["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/" + fname
-                    break
-                except Exception:
-                    pass
-            roof = dict(bound="mfma", kernel=name, launch=dom["name"], achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src,
-                        avg_launch_us=avg_ms * 1e3, launches=dom["launches"],
-                        flop_per_launch=flops_per_launch,
-                        launches_per_step=sum(p["launches"] for p in prof) / psteps,
-                        instrumented_pass="%d updates back to back on one stream (no overlap), HIP events around "
-                                          "every launch (~2.5 us of event overhead inside each figure)" % psteps,
-                        # every launch of one update, HIP-event timed on the launch stream (instrumented pass)
-                        step_launches_us={p["name"]: round(1e3 * p["total_ms"] / psteps, 2) for p in prof if p["launches"]})
-            # SURVEY.md §8(d) asks for both fractions: the HBM-bound launch of the update is the value group's
-            # Adam + Polyak sweep (36 B per parameter + the folded slab combines, algorithmic bytes from the launch site)
-            sweeps = [p for p in prof if p["launches"] and "adam_ema_kernel" in p["name"] and p["bytes"] > 0]
-            if sweeps:
-                sw = max(sweeps, key=lambda p: p["bytes"])
-                sw_ms = sw["total_ms"] / sw["launches"]
-                gbs = sw["bytes"] / sw["launches"] / (sw_ms * 1e-3) / 1e9
-                roof["hbm_bound_launch"] = dict(bound="hbm", launch=sw["name"], achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
-                                                frac=gbs / PEAK_HBM_GBS, avg_launch_us=sw_ms * 1e3,
-                                                bytes_per_launch=sw["bytes"] / sw["launches"])
-
-    if rank == 0:
-        steps_per_s = a.steps / elapsed
+    def line_for(res, steps, warmup):
+        steps_per_s = res["steps_per_s"]
         # weak scaling: every rank pushes one batch-1024 through the update per step, so the whole-job
         # figure counts batch-1024 units of all ranks; one optimizer step consumes `world` of them
         # (its gradient is the mean over the world*1024 rows).  At N=1 the two numbers coincide.
         units_per_s = steps_per_s * world
-        out = {
+        lh = res["lh"]
+        mode = res["mode"]
+        return {
             "metric": "gradient-steps/sec (POR update, batch=%d)" % B,
-            "value": units_per_s, "unit": "gradient-steps/sec", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+            "value": units_per_s, "unit": "gradient-steps/sec", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": 1e3 * res["elapsed"] / steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"POR S={S} A={A} H={H} L={L} B={B}/GPU (global {B * world}), "
                                    f"{rows_per_gpu * world} -row replay ({rows_per_gpu}/GPU) resident in HBM, "
                                    "device sampler + gather + full update per step",
                        "parallelism": f"dp{world}", "global_batch": B * world},
+            "value_counts": "batch-%d units of all ranks per second (= optimizer steps/s x n_gpus: weak scaling)" % B,
             "optimizer_steps_per_sec": steps_per_s,
             "samples_per_sec": steps_per_s * B * world,
             "algorithmic_tflops": steps_per_s * B * world * por_flops_per_sample() / 1e12,
             "final_losses": {"v_loss": float(lh[-1, 0]), "g_loss": float(lh[-1, 1]), "min_nll": float(lh[-1, 2])},
-            "sustained_1000_updates_per_sec": sustained,
-            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
-            "backend": (dist.get_backend() if world > 1 else "none"),
+            "update_mode": ("async_losses + two-stream pipelining (opt-in extensions, INTEGRATION.md); the reference's "
+                            "synchronous convention is secondary.por_sync_mode") if mode == "pipelined" else mode,
+            "setup_spinup_ms": spin_ms,
+            "rccl_ranks": dist.get_world_size() if dp else 1,
+            "backend": (dist.get_backend() if dp else "none"),
         }
-        if roof:
-            out["roofline"] = roof
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            out["speedup_vs_cpu_baseline"] = units_per_s / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+
+    inject = os.environ.get("PORL_BENCH_INJECT", "")                # tests: "die:<mode>" / "hang:<mode>"
+    # -----------------------------------------------------------------------------------------------------------------
+    if dp:
+        modes = [m for m in (os.environ.get("PORL_BENCH_MODES") or ",".join(DP_MODES)).split(",") if m]
+        spinup()
+        results = []
+        for mode in modes:
+            if inject == "die:" + mode and rank == world - 1:
+                os._exit(17)
+            if inject == "hang:" + mode and rank == world - 1:
+                time.sleep(3600)
+            res = timed_run(mode, a.steps, a.warmup)
+            ln = line_for(res, a.steps, a.warmup)
+            ln["dp"] = dict(mode=mode, grad_exchange="all_reduce" if mode == "allreduce_1stream" else "reduce_scatter",
+                            pipelined="pipelined" in mode, policy_process_group=mode.endswith("2comm"),
+                            forced_on_one_rank=bool(force_dp and world == 1))
+            results.append(dict(mode=mode, ok=True, value=ln["value"], ms_per_step=ln["ms_per_step"], line=ln))
+            barrier()                                              # every rank has finished the mode before it is reported
+            if rank == 0:
+                print("PORL_MODE " + json.dumps(results[-1]), flush=True)
+            print("PORL_MODE_DONE " + mode, flush=True)
+        best = max(results, key=lambda r: r["value"])
+        out = dict(best["line"])
+        out["dp"] = dict(out["dp"], modes=[{k: v for k, v in r.items() if k != "line"} for r in results], failed=[],
+                         order="conservative first; `value` = the best mode that finished")
+        barrier()
+        if rank == 0:
+            print("PORL_FINAL " + json.dumps(out), flush=True)
+        # nothing collective after the result: a rank that fails from here on cannot take the line with it
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+        return
+
+    # ---- N = 1 ------------------------------------------------------------------------------------------------------
+    spinup()
+    mode = "one_stream" if a.no_pipeline else "pipelined"
+    res = timed_run(mode, a.steps, a.warmup, keep=True)
+    out = line_for(res, a.steps, a.warmup)
+    agent, one_step = res["agent"], res["one_step"]
+
+    # Not `value`: the same loop again for 1 000 updates, five times, median.  After any idle the card needs ~10 ms of THIS
+    # workload to settle its clocks (scripts/bench_ramp.py: the first ~20 updates after a sync run 10 % slower, whatever
+    # GEMM or streaming spin-up precedes them), and a K = 20 run also pays the pipeline's fill and drain once; a training
+    # job runs millions of updates, so the sustained rate is reported beside the contract's K-step figure.
+    if a.steps < 1000 and os.environ.get("PORL_BENCH_SUSTAINED", "1") != "0":
+        n_s, rates = 1000, []
+        for _ in range(5):
+            barrier()
+            ts = time.perf_counter()
+            for i in range(n_s):
+                one_step(a.warmup + i % a.steps)
+            agent.flush()
+            barrier()
+            rates.append(n_s / (time.perf_counter() - ts))
+        out["sustained_1000_updates_per_sec"] = float(np.median(rates))
+        out["sustained_runs"] = [round(r, 1) for r in rates]
+
+    if not a.no_roofline:
+        out["roofline"] = por_roofline(E, agent, one_step, a, mode)
+    del agent, one_step, res
+
+    if not a.no_secondary and H == 1024 and B == 1024:
+        sec = {}
+        t_sec = time.perf_counter()
+
+        def guarded(name, fn):
+            if time.perf_counter() - t_sec > float(os.environ.get("PORL_BENCH_SECONDARY_BUDGET_S", "150")):
+                sec[name] = {"skipped": "secondary time budget used up"}
+                return
+            try:
+                sec[name] = fn()
+            except Exception as e:                                  # a secondary figure must never take the headline with it
+                sec[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.synchronize()
+
+        def por_variant(mode_, steps, warmup):
+            r = timed_run(mode_, steps, warmup)
+            return dict(value=r["steps_per_s"], ms_per_step=1e3 * r["elapsed"] / steps, steps=steps, warmup=warmup)
+
+        # the reference's calling convention, unchanged por_train.py:79-82: floats come back, one host sync per update
+        guarded("por_sync_mode", lambda: dict(por_variant("sync", max(a.steps, 100), a.warmup),
+                                              note="async_losses=False: everything on one stream, losses returned as "
+                                                   "Python floats every update (what an unmodified por_train.py loop gets)"))
+        guarded("por_one_stream", lambda: dict(por_variant("one_stream", max(a.steps, 100), a.warmup),
+                                               note="async_losses=True, no two-stream pipelining"))
+
+        def h256():
+            global H
+            keep = H
+            H = 256
+            try:
+                r = por_variant("pipelined", max(a.steps, 200), max(a.warmup, 20))
+                r["workload"] = "POR S=60 H=256 (class default, value_functions.py:32) L=2 B=1024, pipelined"
+                return r
+            finally:
+                H = keep
+        guarded("por_h256_b1024", h256)
+        guarded("cql_b4096", lambda: _brief(measure_cql(max(a.steps, 200), max(a.warmup, 20), with_cpu=False)))
+        guarded("sorl_enc_fp32_360x256_b512", lambda: _brief(measure_sorl_enc(max(10, min(a.steps, 20)), 3, 512, 360, 256, "fp32", False)))
+        guarded("sorl_enc_bf16_84x84_b512", lambda: _brief(measure_sorl_enc(max(a.steps, 50), 5, 512, 84, 84, "bf16", False)))
+        guarded("sorl_enc_bf16_360x256_b512", lambda: _brief(measure_sorl_enc(max(10, min(a.steps, 20)), 3, 512, 360, 256, "bf16", False)))
+        out["secondary"] = sec
+
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out), flush=True)
+
+
+def _apply_tuning_env(E):
+    """A/B switches of DESIGN.md §5 (none is set in a default run)."""
+    if os.environ.get("PORL_IQL_FOLD") == "0":                 # slab combines as separate launches
+        E.tune_set("iql_fold", 0)
+    if os.environ.get("PORL_L0_KERNEL") == "0":                # input layers through the grouped GEMM
+        E.tune_set("l0_kernel", 0)
+    for i, v in enumerate(os.environ.get("PORL_TILE_MAP", "").split(",")):      # e.g. "0,1,2,3" = round-1 choice
+        if v.strip():
+            E.tune_set("tile_map%d" % i, int(v))
+            E.tune_set("tile_map_short%d" % i, int(v))
+    if os.environ.get("PORL_IQL_PAD"):                         # "value,policy[,min_blocks]" LDS pads of the pipelined update
+        v = [int(x) for x in os.environ["PORL_IQL_PAD"].split(",")]
+        E.tune_set("iql_pad_value", v[0]); E.tune_set("iql_pad_policy", v[1])
+        if len(v) > 2:
+            E.tune_set("iql_pad_min_blocks", v[2])
+        if len(v) > 3:
+            E.tune_set("iql_pad_min_k", v[3])
+    if os.environ.get("PORL_GEMM_LDS_PAD"):                    # fewer co-resident GEMM blocks per CU (placement knob)
+        E.tune_set("gemm_lds_pad", int(os.environ["PORL_GEMM_LDS_PAD"]))
+    if os.environ.get("PORL_VBWD_TILE"):                       # tile of the value backward in pipelined mode
+        E.tune_set("vbwd_tile_short", int(os.environ["PORL_VBWD_TILE"]))
+    if os.environ.get("PORL_L0_TILE"):                         # tile of the K = 60 forward layers
+        E.tune_set("l0_tile", int(os.environ["PORL_L0_TILE"]))
+    for kv in os.environ.get("PORL_TUNE", "").split(","):      # generic: "key=value,key=value"
+        if "=" in kv:
+            k, v = kv.split("=")
+            E.tune_set(k.strip(), int(v))
+
+
+def por_roofline(E, agent, one_step, a, mode):
+    """Second pass, instrumented: HIP events around every kernel launch on the launch stream.  The timed loop overlaps
+    the policy phase with the next value phase on two streams; a kernel's roofline is quoted with the kernel ALONE on
+    the chip, so this pass runs the same updates back to back on one stream."""
+    agent.flush()
+    agent.pipeline = False
+    psteps = max(a.steps, 100)                 # enough launches for stable per-kernel averages whatever K is
+    E.prof_enable(True)
+    for i in range(psteps):
+        one_step(a.warmup + i % a.steps)
+    prof = E.prof_read()
+    E.prof_enable(False)
+    agent.pipeline = mode == "pipelined"
+    # profile labels are "<launch of the step>:<kernel>".  The roofline is quoted for the DOMINANT LAUNCH of the
+    # update (the labelled launch with the largest total time: the 4-net hidden-layer forward) — one kernel
+    # instantiation can serve launches of very different shapes, which a per-instantiation average would mix
+    gemms = [p for p in prof if p["launches"] and "gemm_f32_kernel" in p["name"]]
+    if not gemms:
+        return None
+    dom = max(gemms, key=lambda p: p["total_ms"])
+    name = dom["name"].split(":")[-1]
+    avg_ms = dom["total_ms"] / dom["launches"]
+    flops_per_launch = dom["flops"] / dom["launches"]
+    ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+    # HBM bytes per launch are NOT measured by this run: they come from the committed rocprofv3 --pmc passes
+    # over this same command (separate passes, as the microarch guide prescribes); the source file is named
+    traffic, traffic_src = None, None
+    for fname in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", fname)))
+            traffic = tj["kernels"][name]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/" + fname
+            break
+        except Exception:
+            pass
+    small = [p for p in prof if p["launches"] and p["flops"] / max(1, p["launches"]) < 2e9]
+    roof = dict(bound="mfma", kernel=name, launch=dom["name"], achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src,
+                avg_launch_us=avg_ms * 1e3, launches=dom["launches"],
+                flop_per_launch=flops_per_launch,
+                launches_per_step=sum(p["launches"] for p in prof) / psteps,
+                instrumented_pass="%d updates back to back on one stream (no overlap), HIP events around "
+                                  "every launch (~2.5 us of event overhead inside each figure)" % psteps,
+                step_sum_us=round(sum(1e3 * p["total_ms"] / psteps for p in prof if p["launches"]), 2),
+                small_launches_us=round(sum(1e3 * p["total_ms"] / psteps for p in small), 2),
+                # every launch of one update, HIP-event timed on the launch stream (instrumented pass)
+                step_launches_us={p["name"]: round(1e3 * p["total_ms"] / psteps, 2) for p in prof if p["launches"]})
+    # SURVEY.md §8(d) asks for both fractions: the HBM-bound launch of the update is the value group's
+    # Adam + Polyak sweep (36 B per parameter + the folded slab combines, algorithmic bytes from the launch site)
+    sweeps = [p for p in prof if p["launches"] and "adam_ema_kernel" in p["name"] and p["bytes"] > 0]
+    if sweeps:
+        sw = max(sweeps, key=lambda p: p["bytes"])
+        sw_ms = sw["total_ms"] / sw["launches"]
+        gbs = sw["bytes"] / sw["launches"] / (sw_ms * 1e-3) / 1e9
+        roof["hbm_bound_launch"] = dict(bound="hbm", launch=sw["name"], achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
+                                        frac=gbs / PEAK_HBM_GBS, avg_launch_us=sw_ms * 1e3,
+                                        bytes_per_launch=sw["bytes"] / sw["launches"])
+    return roof
 
 
 if __name__ == "__main__":

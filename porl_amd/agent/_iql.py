@@ -153,6 +153,9 @@ class IqlAgentBase(nn.Module):
     # slice (N-fold less optimizer traffic) -> all-gather of the parameters (+ a local Polyak sweep for the target);
     # "all_reduce" = SUM all-reduce of the whole group, Adam everywhere.  Same arithmetic per element.
     grad_exchange = "reduce_scatter"
+    # pipelined data-parallel mode: the policy group's collectives on a process group (RCCL communicator) of their own
+    # (see _exchange_for); False keeps ONE communicator — the conservative choice (PORL_DP_POLICY_GROUP=0 sets it too)
+    dp_policy_group = _DP_POLICY_GROUP
 
     def _setup_engine(self, vf: nn.Module, v_target: nn.Module, policy: nn.Module, *, obs_dim, pol_out_dim,
                       hidden_dim, n_hidden, layer_norm, pol_tanh, weight_mode, device, max_batch):
@@ -227,16 +230,17 @@ class IqlAgentBase(nn.Module):
         all-reduce and most of the value-group one overlap with the other phase's kernels."""
         eng, ex = self._engine, self._exchange
         world = ex.world_size
+        dp = ex.active                 # world > 1, or a one-rank group with the exchange forced on (parallel.GradExchange)
         pipelined = self.async_losses and self.pipeline
         if not pipelined:
             eng.join()
         eng._ensure_bound()
         eng.set_mode(((IqlEngine.MODE_TWO_SLOTS | IqlEngine.MODE_SHORT_BLOCKS) if pipelined else 0) |
-                     (IqlEngine.MODE_FOLD_COMBINE if world == 1 else 0))
+                     (IqlEngine.MODE_FOLD_COMBINE if not dp else 0))
         use_sig = pipelined and _PIPE_SYNC in ("signal", "signal2") and eng.signals() is not None
         onecall = _PIPE_ONECALL is True or _PIPE_ONECALL == "1" or (
             _PIPE_ONECALL == "auto" and (batch or 0) * eng.cfg.hidden_dim ** 2 <= _ONECALL_MAX_WORK)
-        if use_sig and world == 1 and replay is not None and onecall:
+        if use_sig and not dp and replay is not None and onecall:
             # the whole update from one native call (csrc: porl_iql_update_pipelined): the same operations on the same
             # two streams in the same order as the phase calls below, without ~12 trips through ctypes per update
             eng._seq += 1
@@ -281,17 +285,17 @@ class IqlAgentBase(nn.Module):
         v_opt.step_count += 1
         p_opt.step_count += 1
         hp = self._hyper(B, v_opt, p_opt)
-        if world == 1 and not pipelined:
+        if not dp and not pipelined:
             eng.step(hp)
             sched.step()
             return self._losses()
         # ---- value phase (current stream) -----------------------------------------------------------------------
         # replay sharded across ranks: each rank's gradients carry 1/B_global, so SUM == global mean
         eng.value_backward(hp)
-        if world > 1 and self._sharded():
+        if dp and self._sharded():
             self._sharded_apply(IqlEngine.GROUP_VF, hp, v_opt)
         else:
-            if world > 1:
+            if dp:
                 v_opt._unshard()
                 ex.allreduce_sum_(eng.grads_vf)
             eng.wait_values_read()             # the PREVIOUS update's policy phase has read the old value nets
@@ -316,10 +320,10 @@ class IqlAgentBase(nn.Module):
                 else:
                     ev_f.record(side)
                 eng.policy_backward(hp)
-                if world > 1 and self._sharded():         # loss statistics stay per-rank shares in this mode
+                if dp and self._sharded():                # loss statistics stay per-rank shares in this mode
                     self._sharded_apply(IqlEngine.GROUP_POL, hp, p_opt, self._exchange_for(IqlEngine.GROUP_POL, True))
                 else:
-                    if world > 1:
+                    if dp:
                         p_opt._unshard()
                         self._exchange_for(IqlEngine.GROUP_POL, True).allreduce_sum_(eng.grads_pol)
                     eng.policy_apply(hp)
@@ -338,7 +342,8 @@ class IqlAgentBase(nn.Module):
                 p_opt._unshard()
                 ex.allreduce_sum_(eng.grads_pol)
                 eng.policy_apply(hp)
-            ex.allreduce_stats_(eng.stats)
+            if not self.async_losses:              # async mode: statistics stay per-rank SHARES (no per-update collective);
+                ex.allreduce_stats_(eng.stats)     # the caller reduces the history once (bench.py)
         sched.step()
         return self._losses()
 
@@ -354,11 +359,11 @@ class IqlAgentBase(nn.Module):
         group therefore gets a process group of its own (same ranks: `dist.new_group()`, created on first use by every
         rank at the same point of the program); PORL_DP_POLICY_GROUP=0 keeps the single group."""
         ex = self._exchange
-        if group != IqlEngine.GROUP_POL or not pipelined or ex.world_size == 1 or not _DP_POLICY_GROUP:
+        if group != IqlEngine.GROUP_POL or not pipelined or not ex.active or not self.dp_policy_group:
             return ex
         if getattr(self, "_exchange_pol", None) is None:
             import torch.distributed as dist
-            self._exchange_pol = GradExchange(dist.new_group())
+            self._exchange_pol = GradExchange(dist.new_group(), force=ex.force)
             # build the new group's communicator now, with nothing else of this agent in flight behind it: one tiny
             # collective and a device synchronisation (once per agent; every rank reaches this point in its first
             # pipelined update)
@@ -407,18 +412,18 @@ class IqlAgentBase(nn.Module):
         eng, ex = self._engine, self._exchange
         eng.join()
         eng._ensure_bound()
-        eng.set_mode(IqlEngine.MODE_FOLD_COMBINE if ex.world_size == 1 else 0)
+        eng.set_mode(IqlEngine.MODE_FOLD_COMBINE if not ex.active else 0)
         B = eng.load_batch(obs, next_obs, rew, term, None)
         v_opt.step_count += 1
         hp = self._hyper(B, v_opt, v_opt)
         eng.value_backward(hp)
-        if ex.world_size > 1 and self._sharded():
+        if ex.active and self._sharded():
             # same exchange as the full update: after a reduce-scatter update a rank holds current Adam moments for its
             # own slice only, so a whole-group Adam here would use stale moments everywhere else
             self._sharded_apply(IqlEngine.GROUP_VF, hp, v_opt)
             ex.allreduce_stats_(eng.stats)
             return
-        if ex.world_size > 1:
+        if ex.active:
             v_opt._unshard()                   # (all_reduce mode after sharded updates: make every slice current first)
             ex.allreduce_sum_(eng.grads_vf)
             ex.allreduce_stats_(eng.stats)

@@ -16,9 +16,26 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
+def _force_default():
+    import os
+    return os.environ.get("PORL_DP_FORCE", "0") == "1"
+
+
 class GradExchange:
-    def __init__(self, group=None):
+    """Collectives of one process group.  `active` decides whether the data-parallel code path runs at all: normally
+    world_size > 1.  `force=True` (or PORL_DP_FORCE=1 in the environment) keeps it active in an initialised process
+    group of ONE rank, so that a single-GPU box can execute the very calls an 8-GPU job makes — reduce-scatter,
+    all-gather, all-reduce on both communicators, from both streams — with RCCL underneath (tests/test_rccl_gpu.py,
+    `bench.py --gpus 1` with PORL_BENCH_FORCE_DP=1).  The arithmetic is unchanged: a SUM over one rank."""
+
+    def __init__(self, group=None, force=None):
         self.group = group
+        self.force = _force_default() if force is None else bool(force)
+
+    @property
+    def active(self):
+        d = _dist()
+        return bool(d) and (d.get_world_size(self.group) > 1 or self.force)
 
     @property
     def world_size(self):
@@ -31,23 +48,22 @@ class GradExchange:
         return d.get_rank(self.group) if d else 0
 
     def allreduce_sum_(self, flat: torch.Tensor):
-        d = _dist()
-        if d and d.get_world_size(self.group) > 1:
+        if self.active:
+            d = _dist()
             d.all_reduce(flat, op=d.ReduceOp.SUM, group=self.group)
         return flat
 
     def allreduce_sum_async(self, flat: torch.Tensor):
         """Start the SUM all-reduce and return its work handle (None when there is nothing to exchange).  The
         collective runs on the backend's own stream; `handle.wait()` orders the current stream behind it."""
-        d = _dist()
-        if d and d.get_world_size(self.group) > 1:
+        if self.active:
+            d = _dist()
             return d.all_reduce(flat, op=d.ReduceOp.SUM, group=self.group, async_op=True)
         return None
 
     def can_shard(self, flat: torch.Tensor):
         """The flat group splits into equal 16-byte-aligned slices for this world size."""
-        w = self.world_size
-        return w > 1 and flat.numel() % (4 * w) == 0
+        return self.active and flat.numel() % (4 * self.world_size) == 0
 
     def slice_of(self, flat: torch.Tensor):
         w, r = self.world_size, self.rank
@@ -68,8 +84,8 @@ class GradExchange:
 
     def allreduce_stats_(self, stats: torch.Tensor):
         """stats[0:2] = (v_loss, g_loss) shares -> SUM; stats[2] = min NLL -> MIN."""
-        d = _dist()
-        if d and d.get_world_size(self.group) > 1:
+        if self.active:
+            d = _dist()
             d.all_reduce(stats[0:2], op=d.ReduceOp.SUM, group=self.group)
             d.all_reduce(stats[2:3], op=d.ReduceOp.MIN, group=self.group)
         return stats

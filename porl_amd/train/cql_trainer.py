@@ -251,7 +251,7 @@ class CQLTrainer:
         g = self.optimizer.param_groups[0]
         hp = eng.hyper(self.gamma, float(self.alpha), 1.0 / (B * ex.world_size), self.optimizer.step_count,
                        g["lr"], g["betas"], g["eps"])
-        if ex.world_size == 1:
+        if not ex.active:
             eng.learn(hp)
         else:
             eng.cql_backward(hp)
@@ -278,7 +278,7 @@ class CQLTrainer:
         draw = self._draws
         self._draws += 1
         eng, ex = self._engine, self._exchange
-        if ex.world_size > 1 or not eng.fused:
+        if ex.active or not eng.fused:
             idx = E.sample_indices(rb.size, self.batch_size, seed, draw, device=self.device)
             return self.learn_on(*rb.gather_device(idx))
         # one-launch path: the step kernel draws the rows itself (or gathers rows idx of the device mirror)

@@ -1,0 +1,85 @@
+"""The RCCL leg of BASELINE config 4 on the ONE GPU of the test box: backend "nccl"
+really initialises, both communicators build, reduce-scatter / all-gather / all-reduce are issued from both streams next
+to the wait-value stream operations, and the numbers equal the plain update.  The multi-rank arithmetic itself is
+covered over gloo (tests/test_dp_gpu.py, tests/test_host_logic.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **kw)
+    return env
+
+
+def test_world1_nccl_exchange_reproduces_the_plain_update():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "helpers", "rccl_world1.py"), str(_free_port())],
+                       env=_env(), capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RCCL_WORLD1 ")]
+    assert len(line) == 1
+    out = json.loads(line[0][len("RCCL_WORLD1 "):])
+    assert out["backend"] == "nccl" and out["world"] == 1
+    assert len(out["cases"]) == 6                       # 2 exchanges x (sync, pipelined x {own communicator, shared})
+    for c in out["cases"]:
+        # the forced path combines split-K slabs in separate launches instead of inside Adam: same sums, other order
+        assert c["max_abs_param_err"] <= 2e-6 and c["max_abs_moment_err"] <= 1e-7, c
+    assert any(c["second_communicator"] for c in out["cases"])
+    h = out["headline"]
+    assert h["max_abs_param_err"] <= 1e-5 and h["max_rel_loss_err"] <= 1e-5, h
+
+
+def test_bench_gpus1_through_rccl():
+    """`bench.py --gpus 1` with PORL_BENCH_FORCE_DP=1: WORLD_SIZE=1, backend nccl, every data-parallel mode of the
+    N > 1 benchmark (conservative first, pipelined two-communicator last) executed on one rank; the line says which
+    modes ran and which one `value` is from."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "3",
+                        "--rows-per-gpu", "50000", "--no-roofline", "--no-cpu-baseline", "--no-secondary"],
+                       env=_env(PORL_BENCH_FORCE_DP="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["backend"] == "nccl" and out["rccl_ranks"] == 1 and out["dp"]["forced_on_one_rank"] is True
+    modes = {m["mode"]: m for m in out["dp"]["modes"]}
+    assert set(modes) == {"allreduce_1stream", "reduce_scatter_1stream", "reduce_scatter_pipelined_1comm",
+                          "reduce_scatter_pipelined_2comm"}
+    assert all(m["ok"] and np.isfinite(m["value"]) for m in modes.values())
+    assert out["dp"]["mode"] in modes and out["value"] == modes[out["dp"]["mode"]]["value"]
+    assert out["dp"]["grad_exchange"] in ("reduce_scatter", "all_reduce")
+    assert isinstance(out["dp"]["policy_process_group"], bool) and isinstance(out["dp"]["pipelined"], bool)
+
+
+def test_bench_supervisor_falls_back_when_the_aggressive_mode_dies():
+    """The supervisor (a parent that makes no GPU call) keeps the conservative modes' results when a later mode kills or
+    hangs the rank processes: injected here with PORL_BENCH_INJECT=die:<mode> / hang:<mode> (two gloo ranks on the
+    box's one GPU).  The line must come from a mode that finished and must say what happened to the other."""
+    for inject, deadline in (("die:reduce_scatter_pipelined_2comm", "200"), ("hang:reduce_scatter_pipelined_1comm", "25")):
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                            "--rows-per-gpu", "20000", "--no-roofline"],
+                           env=_env(PORL_BENCH_BACKEND="gloo", PORL_BENCH_INJECT=inject, PORL_BENCH_MODE_DEADLINE_S=deadline),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (inject, r.stdout[-1500:], r.stderr[-3000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, inject
+        out = json.loads(lines[0])
+        bad = inject.split(":")[1]
+        assert out["dp"]["mode"] != bad and out["n_gpus"] == 2
+        assert bad in out["dp"]["failed"] or bad in str(out["dp"].get("note", "")), out["dp"]
+        assert np.isfinite(out["value"])
