@@ -89,6 +89,8 @@ def main():
     assert np.isfinite(res[True][1]).all()
     out["headline"] = dict(updates=K, plain_ms_per_update=1e3 * res[False][0] / K, rccl_ms_per_update=1e3 * res[True][0] / K,
                            max_abs_param_err=max(float((res[True][2][k] - res[False][2][k]).abs().max()) for k in res[True][2]),
+                           frac_params_beyond_2e6=float(sum(int(((res[True][2][k] - res[False][2][k]).abs() > 2e-6).sum())
+                                                            for k in res[True][2]) / sum(v.numel() for v in res[True][2].values())),
                            max_rel_loss_err=float(np.abs(res[True][1][:, :2] / res[False][1][:, :2] - 1).max()))
     torch.cuda.synchronize()
     dist.destroy_process_group()

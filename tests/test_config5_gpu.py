@@ -14,9 +14,9 @@ reference at 360x256 / fp32 (tests/test_oracle_golden.py), the 84x84 oracle is t
 constants replaced, and the HIP fp32 path is compared with it here at full batch.
 
 bf16 bound (this build's, stated): features within 3e-2 of the largest fp32 feature magnitude; losses within 2e-2
-relative; parameters after three Adam steps within 3.2e-4 (three steps of lr = 1e-4: Adam's first steps move a weight
-by ~lr whatever the gradient's size, so a sign decided by bf16 noise costs up to 2*lr per step on that weight) with a
-mean absolute deviation below 3e-5.
+relative; parameters after three Adam steps within 6.2e-4 (Adam's first steps move a weight by ~lr = 1e-4 whatever the
+gradient's size, so a gradient sign decided by bf16 noise costs up to 2*lr per step on that weight: 3 x 2e-4; measured
+4.8e-4) with a MEAN absolute deviation below 3e-5 (the assertion that carries the information).
 """
 import os
 import sys
@@ -151,7 +151,7 @@ def test_sorl_update_with_84x84_encoder_bf16_b512_vs_fp32_oracle_and_properties(
         worst = max(worst, float(err.max()))
         mean_dev += float(err.sum())
         n_all += err.size
-    assert worst <= 3.2e-4, worst
+    assert worst <= 6.2e-4, worst
     assert mean_dev / n_all <= 3e-5, mean_dev / n_all
     for k, ref in ref_stats.items():
         if "running_var" in k:
