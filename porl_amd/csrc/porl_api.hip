@@ -15,6 +15,7 @@
 #include "gemm_bf16.hpp"
 #include "kernels.hpp"
 #include "l0_fwd.hpp"
+#include "skinny.hpp"
 #include "qnet_fused.hpp"
 #include "per_tree.hpp"
 #include "dist_losses.hpp"
@@ -120,6 +121,7 @@ thread_local bool g_short_blocks = false;       // set by the IQL entry points f
 int g_vbwd_tile_short = -1;   // porl_tune_set("vbwd_tile_short", t): tile of the value nets' hidden-layer backward in short-block mode (A/B)
 int g_l0_kernel = 1;        // porl_tune_set("l0_kernel", 0): input layers (K <= 64) through the grouped GEMM instead of l0_fwd_kernel (A/B, bit-identical)
 int g_l0_tile = -1;          // porl_tune_set("l0_tile", t): tile override for the K <= 128 forward layers of the IQL step (A/B)
+int g_skinny = 1;            // porl_tune_set("skinny", 0): the <= 64-wide products of the IQL step (dW0, policy mean, output-layer backward) through the grouped GEMM instead of skinny.hpp (A/B; same sums, other order inside a 64-chunk)
 int g_iql_fold = 1;          // porl_tune_set("iql_fold", 0): porl_iql_step keeps the slab combines as launches of their own (A/B)
 int g_enc_bn_sweep = 0;      // porl_tune_set("enc_bn_sweep", 1): BatchNorm + ReLU of the MLP blocks as a separate sweep (cross-check)
 int g_enc_dense_patch = 0;   // porl_tune_set("enc_dense_patch", 1): rasterise + dense patch embedding (cross-check)
@@ -667,6 +669,38 @@ int porl_iql_set_stats(porl_iql* h, float* stats) {
   return PORL_OK;
 }
 
+
+// Input-layer weight gradients dW0 = dZ0^T X (+ db0) of up to 4 nets on wgrad_skinny_kernel (skinny.hpp): slabs over
+// batch chunks in the split-K layout, combine jobs appended to `red`.  Returns false when the shapes do not qualify
+// (the caller then takes the grouped-GEMM path).
+struct Dw0Net { const float* dz; float* gw; float* gb; float* slabW; float* slabC; };
+static bool dw0_skinny(const Dw0Net* nets, int nnets, const float* X, int ldx, int B, int H, int S, int ldz, ReduceArgs& red,
+                       const char* phase, hipStream_t s, int* rc) {
+  *rc = 0;
+  if (!g_skinny || S > SKN_T || nnets > SKN_MAX_NETS || H % 4 || !skn_ok4(X, ldx) || ldz % 4) return false;
+  for (int i = 0; i < nnets; ++i) if (!skn_ok4(nets[i].dz, ldz)) return false;
+  WgradSkinnyArgs a{};
+  a.nnets = nnets; a.B = B; a.H = H; a.S = S; a.ldz = ldz; a.ldx = ldx; a.ldo = S;
+  a.tiles_n = cdiv(H, SKN_T);
+  skn_split(cdiv(B, SKN_T), SK_MAX, a.nslab, a.rtiles);
+  a.slabW_stride = (long)H * S; a.slabC_stride = H;
+  for (int i = 0; i < nnets; ++i) {
+    a.net[i] = WgradSkinnyNet{nets[i].dz, X, nets[i].slabW, nets[i].slabC};
+    add_reduce(red, nets[i].gw, nets[i].slabW, (long)H * S, (long)H * S, a.nslab);
+    add_reduce(red, nets[i].gb, nets[i].slabC, H, H, a.nslab);
+  }
+  g_phase = phase;
+  {
+    ProfScope ps("wgrad_skinny_kernel", s, 2.0 * nnets * B * (double)H * S,
+                 4.0 * nnets * ((double)B * H + (double)B * S + (double)a.nslab * H * (S + 1)));
+    hipLaunchKernelGGL(wgrad_skinny_kernel, dim3(nnets * a.nslab * a.tiles_n), dim3(256), 0, s, a);
+  }
+  g_phase = "";
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_err = std::string("wgrad_skinny_kernel: ") + hipGetErrorString(e); *rc = (int)e; }
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // `defer` (optional): the final combine launch is not issued; its jobs are handed to the caller, who folds them into
 // the Adam launch (porl_iql_step).
@@ -747,6 +781,20 @@ static int value_backward_impl(porl_iql* h, const porl_iql_hyper* hp, hipStream_
   }
   for (int l = L - 1; l >= 0; --l) {
     const int Kin = l == 0 ? S : H;
+    if (l == 0) {
+      // skinny (H x S) weight gradient on its own kernel: one 64 x 64 tile of dZ0 per block, slabs over batch chunks
+      Dw0Net dn[2];
+      const int64_t per = (int64_t)H * S, perc = H;
+      for (int i = 0; i < 2; ++i) {
+        float* slabW = W + ws.slab_a + (int64_t)i * SK_MAX * (per + 2 * perc + 8);
+        dn[i] = Dw0Net{W + ws.dz_v[i][0], Gv + h->v[i].w[0], Gv + h->v[i].b[0], slabW, slabW + (int64_t)SK_MAX * per};
+      }
+      int rc = 0;
+      if (dw0_skinny(dn, 2, W + ws.xs_slot[h->slot], h->Sp, B, H, S, Hp, red, "V6.dW0:", s, &rc)) {
+        if (rc) return rc;
+        break;
+      }
+    }
     GemmGroup g{};
     for (int i = 0; i < 2; ++i) {
       const float* dz = W + ws.dz_v[i][l & 1];
@@ -886,6 +934,22 @@ int porl_iql_policy_apply(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
 static int policy_mean_slabs(porl_iql* h, int B, int* nslab, hipStream_t s) {
   const int H = h->cfg.hidden_dim, D = h->cfg.pol_out_dim, L = h->cfg.n_hidden;
   float* W = h->buf.workspace;
+  if (g_skinny && D <= SKN_T && H % 4 == 0 && skn_ok4(W + h->ws.act_p[L - 1], h->Hp) &&
+      skn_ok4(h->buf.params_pol + h->pol.w[L], H) && h->Dp % 4 == 0) {
+    MeanSkinnyArgs a{};
+    a.A = W + h->ws.act_p[L - 1]; a.W = h->buf.params_pol + h->pol.w[L]; a.slab = W + h->ws.slab_mean;
+    a.B = B; a.H = H; a.D = D; a.lda = h->Hp; a.ldw = H; a.ldo = h->Dp;
+    a.tiles_m = cdiv(B, SKN_T);
+    // few row tiles (small batches): more slabs keep the chip busy; at B >= 1024 eight 128-deep slabs halve what the
+    // NLL kernel reads back
+    skn_split(cdiv(H, SKN_T), a.tiles_m >= 16 ? SK_MAX / 2 : SK_MAX, a.nslab, a.ktiles);
+    a.slab_stride = (long)B * h->Dp;
+    *nslab = a.nslab;
+    ProfScope ps("mean_skinny_kernel", s, 2.0 * B * (double)H * D, 4.0 * ((double)B * H + (double)D * H + (double)a.nslab * B * h->Dp));
+    hipLaunchKernelGGL(mean_skinny_kernel, dim3(a.tiles_m * a.nslab), dim3(256), 0, s, a);
+    PORL_HIP(hipGetLastError());
+    return 0;
+  }
   GemmGroup g{};
   g.nprob = 1;
   g.p[0] = make_prob(GEMM_NT, W + h->ws.act_p[L - 1], h->Hp, h->buf.params_pol + h->pol.w[L], H, W + h->ws.slab_mean,
@@ -1000,7 +1064,27 @@ static int policy_backward_impl(porl_iql* h, const porl_iql_hyper* hp, hipStream
   add_reduce(red, Gp + h->logstd_off, W + ws.part_dls, D, D, nblk);            // d/dlog_std (already clamp-masked)
   add_reduce(red, h->buf.stats + 1, W + ws.part_loss, 1, 1, nblk);            // stats[1] = g_loss
   add_reduce(red, h->buf.stats + 2, W + ws.part_min, 1, 1, nblk, /*min*/ 1);  // stats[2] = min NLL
-  {
+  if (g_skinny && D <= SKN_T && H % 4 == 0 && Dp % 4 == 0 && Hp % 4 == 0 && skn_ok4(Pp + h->pol.w[L], H)) {
+    // output layer on out_bwd_kernel (skinny.hpp): one pass over the last hidden activation gives dZ_{L-1} and the
+    // dW_L / db_L slabs
+    OutBwdArgs a{};
+    a.dmu = W + ws.dmu; a.W = Pp + h->pol.w[L]; a.A = W + ws.act_p[L - 1];
+    a.dZ = W + ws.dz_p[(L - 1) & 1];
+    a.slabW = W + ws.slab_b; a.slabC = a.slabW + (int64_t)SK_MAX * D * H;
+    a.B = B; a.H = H; a.D = D; a.lddmu = Dp; a.ldw = H; a.lda = Hp; a.lddz = Hp;
+    a.tiles_n = cdiv(H, SKN_T);
+    skn_split(cdiv(B, SKN_T), SK_MAX, a.nslab, a.rtiles);
+    a.slabW_stride = (long)D * H; a.slabC_stride = D;
+    add_reduce(red, Gp + h->pol.w[L], a.slabW, (long)D * H, (long)D * H, a.nslab);
+    add_reduce(red, Gp + h->pol.b[L], a.slabC, D, D, a.nslab);
+    g_phase = "P5.outbwd:";
+    {
+      ProfScope ps("out_bwd_kernel", s, 4.0 * B * (double)H * D, 4.0 * (2.0 * B * H + (double)B * D + (double)D * H + (double)a.nslab * D * H));
+      hipLaunchKernelGGL(out_bwd_kernel, dim3(a.nslab * a.tiles_n), dim3(256), 0, s, a);
+    }
+    g_phase = "";
+    PORL_HIP(hipGetLastError());
+  } else {
     // output layer: dW_L = dmu^T H_{L-1} (D x H, skinny M), and dZ_{L-1} = (dmu W_L) . 1[H_{L-1} > 0]
     GemmGroup g{};
     g.nprob = 2;
@@ -1024,6 +1108,16 @@ static int policy_backward_impl(porl_iql* h, const porl_iql_hyper* hp, hipStream
   }
   for (int l = L - 1; l >= 0; --l) {
     const int Kin = l == 0 ? S : H;
+    if (l == 0) {
+      const int64_t per = (int64_t)H * S;
+      float* slabW = W + ws.slab_pa;
+      Dw0Net dn{W + ws.dz_p[0], Gp + h->pol.w[0], Gp + h->pol.b[0], slabW, slabW + (int64_t)SK_MAX * per};
+      int rc = 0;
+      if (dw0_skinny(&dn, 1, W + ws.xs_slot[h->slot], h->Sp, B, H, S, Hp, red, "P7.dW0:", s, &rc)) {
+        if (rc) return rc;
+        break;
+      }
+    }
     const float* dz = W + ws.dz_p[l & 1];
     const float* in = l == 0 ? W + ws.xs_slot[h->slot] : W + ws.act_p[l - 1];
     const int ldin = l == 0 ? h->Sp : Hp;
@@ -1380,6 +1474,7 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "enc_s2d")) { g_enc_s2d = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_bn_sweep")) { g_enc_bn_sweep = value != 0; return PORL_OK; }
   if (!strcmp(key, "iql_fold")) { g_iql_fold = value != 0; return PORL_OK; }
+  if (!strcmp(key, "skinny")) { g_skinny = value != 0; return PORL_OK; }
   if (!strcmp(key, "l0_tile")) { g_l0_tile = value; return PORL_OK; }
   if (!strcmp(key, "l0_kernel")) { g_l0_kernel = value != 0; return PORL_OK; }
   if (!strcmp(key, "vbwd_tile_short")) { g_vbwd_tile_short = value; return PORL_OK; }

@@ -117,8 +117,17 @@ def _cmp_grads(named, views, ref, tag):
         r = ref[n]
         scale = max(1e-30, float(np.abs(r).max()))
         err = np.abs(g.cpu().numpy().astype(np.float64) - r) / scale
-        # a flipped ReLU mask bit changes one row by a few % of the largest gradient: allow a 1e-3 fraction
-        assert float((err > 2e-5).mean()) <= 1e-3, f"{tag}: grad {n}: {(err > 2e-5).mean():.2e} of elements off"
+        # A flipped ReLU mask bit (fp32 vs fp64 pre-activation within ~1e-7 of zero) changes one row by a few % of the
+        # largest gradient: allow a 1e-3 fraction beyond 2e-5.  When the flipped unit sits in an UPPER layer of a sample with
+        # a large advantage weight (up to 100x), that one sample's change reaches every element of the lower layers'
+        # gradients at the 1e-5..1e-4 level (seen at S=60 H=512 L=3 B=2048: 15 % of dW0 beyond 2e-5 on one of two
+        # trajectories that differ only by rounding; from identical state the kernels agree with the round-2 path to
+        # 1e-7, scripts/dbg/skinny_ab2.py).  That signature — median error at rounding level, errors beyond 1e-3 rare — is
+        # accepted too; an indexing or summation bug moves the median or puts many elements beyond 1e-3.
+        frac = float((err > 2e-5).mean())
+        flip_signature = float(np.median(err)) <= 5e-6 and float((err > 1e-3).mean()) <= 1e-3
+        assert frac <= 1e-3 or flip_signature, (f"{tag}: grad {n}: {frac:.2e} of elements beyond 2e-5, median "
+                                                f"{np.median(err):.2e}, {(err > 1e-3).mean():.2e} beyond 1e-3")
         assert float(err.max()) < 5e-2, f"{tag}: grad {n} rel-to-max error {err.max():.2e}"
 
 
@@ -582,3 +591,50 @@ def test_adam_sweep_over_an_empty_range_is_a_no_op():
     N.check(N.lib().porl_adam_ema(p, g, m, v, None, 0, 1e-3, 1, 0.9, 0.999, 1e-8, 0.0, N.current_stream_ptr(buf)), "porl_adam_ema")
     torch.cuda.synchronize()
     assert (buf == 3.0).all()
+
+
+@pytest.mark.parametrize("S,H,L,B,sorl", [(60, 1024, 2, 1024, False), (17, 48, 3, 50, False), (60, 256, 2, 130, True),
+                                          (64, 192, 1, 2100, False), (8, 72, 2, 64, True), (60, 512, 3, 2048, False)])
+def test_skinny_kernels_agree_with_the_grouped_gemm_path(S, H, L, B, sorl):
+    """The <= 64-wide products of the step (input-layer weight gradients, policy mean, policy output-layer backward) run
+    on csrc/skinny.hpp; porl_tune_set("skinny", 0) sends them through the grouped GEMM as in round 2.  Same partial sums
+    per 64-chunk in another order, so from IDENTICAL state (three updates; both paths' backward passes run on every
+    update before the parameters move) gradients and losses agree to fp32 rounding.  Covers ragged shapes, more than 16
+    row tiles (several tiles per slab) and SORL's 2-wide output layer; both paths are pinned to the reference by the
+    golden tests above.  (Whole trajectories are NOT compared: Adam's first steps turn a 1e-10 gradient difference on
+    a |g| ~ 1e-8 entry into a 1e-6 parameter difference, and ReLU-mask flips do the rest.)"""
+    from porl_amd import engine as E
+    from porl_amd.agent.sorl import SORL
+    from porl_amd.engine import IqlEngine
+    A = 2
+    rows = torch.from_numpy(make_rows(3 * B, S, A, seed=31)).to(DEV)
+    if sorl:
+        torch.manual_seed(0)
+        agent = SORL(_args(S, H, L, A=A, B=B), 1000, 0.9, 3.0, device=DEV)
+        v_opt, p_opt, sched = agent.v_optimizer, agent.policy_optimizer, agent.lr_schedule
+    else:
+        agent = _make_por(S, H, L, B)
+        v_opt, p_opt, sched = agent.v_optimizer, agent.goal_policy_optimizer, agent.goal_lr_schedule
+    eng = agent._engine
+    try:
+        for k in range(3):
+            s, r, sp, d, a = split_rows(rows[k * B:(k + 1) * B], S, A)
+            Bk = eng.load_batch(s, sp, r, d, a if sorl else sp)
+            v_opt.step_count += 1
+            p_opt.step_count += 1
+            hp = agent._hyper(Bk, v_opt, p_opt)
+            for phase, group, apply in (("value_backward", 0, "value_apply"), ("policy_backward", 1, "policy_apply")):
+                got = {}
+                for skinny in (0, 1):
+                    E.tune_set("skinny", skinny)
+                    getattr(eng, phase)(hp)
+                    flat = eng.grads_vf if group == 0 else eng.grads_pol
+                    got[skinny] = ([g.clone() for g in IqlEngine.views(flat, eng.tensor_table(group))], eng.stats[:3].clone())
+                for i, (g0, g1) in enumerate(zip(got[0][0], got[1][0])):
+                    scale = float(g0.abs().max())
+                    assert float((g0 - g1).abs().max()) <= 1e-6 * scale + 1e-12, (k, phase, i, scale)
+                np.testing.assert_allclose(got[1][1].cpu().numpy(), got[0][1].cpu().numpy(), rtol=1e-6)
+                getattr(eng, apply)(hp)
+            sched.step()
+    finally:
+        E.tune_set("skinny", 1)
