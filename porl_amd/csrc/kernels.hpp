@@ -115,6 +115,7 @@ struct PolicyNllArgs {
 };
 
 constexpr int NLL_MAX_COLS_PER_LANE = 8;   // D <= 512
+constexpr int NLL_FAST_SLABS = 16;
 
 __global__ __launch_bounds__(256) void policy_nll_kernel(const PolicyNllArgs a) {
   __shared__ float sh_dls[4][NLL_MAX_COLS_PER_LANE * 64];
@@ -142,7 +143,46 @@ __global__ __launch_bounds__(256) void policy_nll_kernel(const PolicyNllArgs a) 
   float loss_acc = 0.f, min_acc = INFINITY;
   const int row0 = blockIdx.x * a.rows_per_block;
   const int row1 = min(a.B, row0 + a.rows_per_block);
-  for (int b = row0 + wave; b < row1; b += 4) {
+  // Common shape (D <= 64, at most NLL_FAST_SLABS mean slabs, at most 64 head partials): every load of a row is issued
+  // before the first use — head partials, TD target, all slabs, the regression target: ONE round trip per row instead
+  // of a chain of three (the kernel is one wave per row and nothing else hides the latency).  Same sums in the same
+  // order as the general loop below.
+  const bool fast = ncl == 1 && a.nslab <= NLL_FAST_SLABS && a.parts <= 64;
+  for (int b = row0 + wave; fast && b < row1; b += 4) {
+    const bool pv = lane < a.parts, cv = lane < a.D;
+    const float h0 = a.hp_v[0][pv ? (size_t)lane * a.B + b : 0], h1 = a.hp_v[1][pv ? (size_t)lane * a.B + b : 0];
+    const float tv = a.target_v[b];
+    float ms[NLL_FAST_SLABS];
+#pragma unroll
+    for (int s = 0; s < NLL_FAST_SLABS; ++s) {
+      const bool ok = cv && s < a.nslab;
+      const float x = a.mean_slab[ok ? (size_t)s * a.slab_stride + (size_t)b * a.ldm + lane : 0];
+      ms[s] = ok ? x : 0.f;
+    }
+    const float xv = a.x[cv ? (size_t)b * a.ldx + lane : 0];
+    const float v0 = wave_sum(pv ? h0 : 0.f), v1 = wave_sum(pv ? h1 : 0.f);
+    const float adv = tv - fminf(v0 + bv0, v1 + bv1);
+    const float wgt = fminf(expf(a.weight_mode ? a.alpha * adv : adv / a.alpha), EXP_ADV_MAX);
+    const float wb = wgt * a.inv_batch;
+    float m = ms[0];
+#pragma unroll
+    for (int s = 1; s < NLL_FAST_SLABS; ++s)
+      if (s < a.nslab) m += ms[s];
+    m += mb[0];
+    if (a.tanh_mean) m = tanhf(m);
+    const float z = cv ? (xv - m) * isg[0] : 0.f;
+    const float zz = wave_sum(z * z);
+    const float nlp = half_log2pi_D + 0.5f * zz + lsig;
+    loss_acc += wb * nlp;
+    min_acc = fminf(min_acc, nlp);
+    if (cv) {
+      float dm = -wb * z * isg[0];
+      if (a.tanh_mean) dm *= (1.f - m * m);
+      a.dmean[(size_t)b * a.ldd + lane] = dm;
+      dls[0] += wb * (1.f - z * z);
+    }
+  }
+  for (int b = row0 + wave; !fast && b < row1; b += 4) {
     // head partial sums: lane p takes part p (parts <= 64), then a wave reduction — one load deep
     float v0 = 0.f, v1 = 0.f;
     for (int p = lane; p < a.parts; p += 64) {
@@ -255,10 +295,22 @@ __device__ __forceinline__ float reduce_chunk(const ReduceJob& j, long i0, float
   const float s = j.op ? fminf(fminf(s0, s1), fminf(s2, s3)) : (s0 + s1) + (s2 + s3);
   sh[ty * (W + 1) + tx] = s;
   __syncthreads();
+  if (W == 4) {
+    // 64 slab lanes per output: wave w gathers the 64 partials of output w and combines them with the butterfly of
+    // wave_sum / wave_min — a fixed tree, six steps deep, instead of a 63-long chain of dependent LDS reads and adds on
+    // one thread (that chain, ~4 us, was the critical path of the Adam launches that fold these combines in)
+    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    float v = sh[ln * (W + 1) + w];
+    v = j.op ? wave_min(v) : wave_sum(v);
+    __syncthreads();
+    if (ln == 0) sh[w] = v;
+    __syncthreads();
+  }
   float t = 0.f;
   if (ty == 0 && i < j.n) {
     t = sh[tx];
-    for (int q = 1; q < L; ++q) t = j.op ? fminf(t, sh[q * (W + 1) + tx]) : t + sh[q * (W + 1) + tx];
+    if (W != 4)
+      for (int q = 1; q < L; ++q) t = j.op ? fminf(t, sh[q * (W + 1) + tx]) : t + sh[q * (W + 1) + tx];
     t *= j.scale;
     if (j.bias) t += j.bias[i % j.ncols];
     if (j.act == 1) t = fmaxf(t, 0.f);

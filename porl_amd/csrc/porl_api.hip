@@ -121,7 +121,17 @@ thread_local bool g_short_blocks = false;       // set by the IQL entry points f
 int g_vbwd_tile_short = -1;   // porl_tune_set("vbwd_tile_short", t): tile of the value nets' hidden-layer backward in short-block mode (A/B)
 int g_l0_kernel = 1;        // porl_tune_set("l0_kernel", 0): input layers (K <= 64) through the grouped GEMM instead of l0_fwd_kernel (A/B, bit-identical)
 int g_l0_tile = -1;          // porl_tune_set("l0_tile", t): tile override for the K <= 128 forward layers of the IQL step (A/B)
-int g_skinny = 1;            // porl_tune_set("skinny", 0): the <= 64-wide products of the IQL step (dW0, policy mean, output-layer backward) through the grouped GEMM instead of skinny.hpp (A/B; same sums, other order inside a 64-chunk)
+// porl_tune_set("skinny", mask): which of the <= 64-wide products of the IQL step run on skinny.hpp instead of the grouped
+// GEMM — bit 0: input-layer weight gradients dW0, bit 1: policy mean, bit 2: policy output-layer backward; 0 = round 2's
+// path (A/B; same sums, other order inside a 64-chunk), 1 is read as "all" (7)
+int g_skinny = 7;
+// The same mask for the PIPELINED update (PORL_IQL_MODE_SHORT_BLOCKS), porl_tune_set("skinny_pipelined", mask).  Default 0:
+// there the policy phase is not the critical stream, and shortening its launches moved the two queues against each other
+// — same-box A/B (gpurun_out/r03/ab3.log, sustained updates/s, two runs each): mask 0: 3 306 / 3 309; 7: 3 206 / 3 204; 4:
+// 3 233 / 3 238; 6: 3 221 / 3 218 — while the one-stream update gains 10-12 us (380 -> 369 us event-timed).
+int g_skinny_pipelined = 0;
+inline int skinny_mask() { return g_short_blocks ? g_skinny_pipelined : g_skinny; }
+int g_dw0_slabs = 16;        // porl_tune_set("dw0_slabs", n <= SK_MAX): slabs of the skinny dW0 kernel (A/B: fewer slabs = fewer partial bytes, fewer blocks)
 int g_iql_fold = 1;          // porl_tune_set("iql_fold", 0): porl_iql_step keeps the slab combines as launches of their own (A/B)
 int g_enc_bn_sweep = 0;      // porl_tune_set("enc_bn_sweep", 1): BatchNorm + ReLU of the MLP blocks as a separate sweep (cross-check)
 int g_enc_dense_patch = 0;   // porl_tune_set("enc_dense_patch", 1): rasterise + dense patch embedding (cross-check)
@@ -677,12 +687,12 @@ struct Dw0Net { const float* dz; float* gw; float* gb; float* slabW; float* slab
 static bool dw0_skinny(const Dw0Net* nets, int nnets, const float* X, int ldx, int B, int H, int S, int ldz, ReduceArgs& red,
                        const char* phase, hipStream_t s, int* rc) {
   *rc = 0;
-  if (!g_skinny || S > SKN_T || nnets > SKN_MAX_NETS || H % 4 || !skn_ok4(X, ldx) || ldz % 4) return false;
+  if (!(skinny_mask() & 1) || S > SKN_T || nnets > SKN_MAX_NETS || H % 4 || !skn_ok4(X, ldx) || ldz % 4) return false;
   for (int i = 0; i < nnets; ++i) if (!skn_ok4(nets[i].dz, ldz)) return false;
   WgradSkinnyArgs a{};
   a.nnets = nnets; a.B = B; a.H = H; a.S = S; a.ldz = ldz; a.ldx = ldx; a.ldo = S;
   a.tiles_n = cdiv(H, SKN_T);
-  skn_split(cdiv(B, SKN_T), SK_MAX, a.nslab, a.rtiles);
+  skn_split(cdiv(B, SKN_T), g_dw0_slabs, a.nslab, a.rtiles);
   a.slabW_stride = (long)H * S; a.slabC_stride = H;
   for (int i = 0; i < nnets; ++i) {
     a.net[i] = WgradSkinnyNet{nets[i].dz, X, nets[i].slabW, nets[i].slabC};
@@ -934,7 +944,7 @@ int porl_iql_policy_apply(porl_iql* h, const porl_iql_hyper* hp, void* stream) {
 static int policy_mean_slabs(porl_iql* h, int B, int* nslab, hipStream_t s) {
   const int H = h->cfg.hidden_dim, D = h->cfg.pol_out_dim, L = h->cfg.n_hidden;
   float* W = h->buf.workspace;
-  if (g_skinny && D <= SKN_T && H % 4 == 0 && skn_ok4(W + h->ws.act_p[L - 1], h->Hp) &&
+  if ((skinny_mask() & 2) && D <= SKN_T && H % 4 == 0 && skn_ok4(W + h->ws.act_p[L - 1], h->Hp) &&
       skn_ok4(h->buf.params_pol + h->pol.w[L], H) && h->Dp % 4 == 0) {
     MeanSkinnyArgs a{};
     a.A = W + h->ws.act_p[L - 1]; a.W = h->buf.params_pol + h->pol.w[L]; a.slab = W + h->ws.slab_mean;
@@ -1064,7 +1074,7 @@ static int policy_backward_impl(porl_iql* h, const porl_iql_hyper* hp, hipStream
   add_reduce(red, Gp + h->logstd_off, W + ws.part_dls, D, D, nblk);            // d/dlog_std (already clamp-masked)
   add_reduce(red, h->buf.stats + 1, W + ws.part_loss, 1, 1, nblk);            // stats[1] = g_loss
   add_reduce(red, h->buf.stats + 2, W + ws.part_min, 1, 1, nblk, /*min*/ 1);  // stats[2] = min NLL
-  if (g_skinny && D <= SKN_T && H % 4 == 0 && Dp % 4 == 0 && Hp % 4 == 0 && skn_ok4(Pp + h->pol.w[L], H)) {
+  if ((skinny_mask() & 4) && D <= SKN_T && H % 4 == 0 && Dp % 4 == 0 && Hp % 4 == 0 && skn_ok4(Pp + h->pol.w[L], H)) {
     // output layer on out_bwd_kernel (skinny.hpp): one pass over the last hidden activation gives dZ_{L-1} and the
     // dW_L / db_L slabs
     OutBwdArgs a{};
@@ -1474,7 +1484,9 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "enc_s2d")) { g_enc_s2d = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_bn_sweep")) { g_enc_bn_sweep = value != 0; return PORL_OK; }
   if (!strcmp(key, "iql_fold")) { g_iql_fold = value != 0; return PORL_OK; }
-  if (!strcmp(key, "skinny")) { g_skinny = value != 0; return PORL_OK; }
+  if (!strcmp(key, "skinny")) { g_skinny = value == 1 ? 7 : value; return PORL_OK; }
+  if (!strcmp(key, "skinny_pipelined")) { g_skinny_pipelined = value == 1 ? 7 : value; return PORL_OK; }
+  if (!strcmp(key, "dw0_slabs")) { g_dw0_slabs = std::max(1, std::min(value, SK_MAX)); return PORL_OK; }
   if (!strcmp(key, "l0_tile")) { g_l0_tile = value; return PORL_OK; }
   if (!strcmp(key, "l0_kernel")) { g_l0_kernel = value != 0; return PORL_OK; }
   if (!strcmp(key, "vbwd_tile_short")) { g_vbwd_tile_short = value; return PORL_OK; }
