@@ -384,7 +384,11 @@ typedef struct porl_enc_cfg {
   /* 0 (default, the parity path): fp32 operands on the fp32-input MFMA.  1: the 1x1 / merge convolutions round their
    * operands to bf16 on the way into LDS and multiply on the bf16 matrix pipe, fp32 accumulate; activations, BatchNorm
    * statistics, the partial 3x3 conv, the patch embedding and the two head products stay fp32.  The reference has no
-   * bf16 path (fp32 everywhere): results then differ from it by bf16 rounding (tests state the tolerance). */
+   * bf16 path (fp32 everywhere): results then differ from it by bf16 rounding (tests state the tolerance).
+   * 2: bf16 ACTIVATIONS in HBM behind the patch embedding; partial 3x3 conv, MLP blocks (fused: one kernel per pass over
+   * x) and the 2x2s2 merge on the bf16 matrix pipe, fp32 accumulate, fp32 BatchNorm statistics and head
+   * (csrc/encoder_bf16.hpp).  Instantiated for the reference architecture (embed 96, mlp_ratio 2, n_div 4); other shapes
+   * run mode 1. */
   int32_t bf16_operands;
 } porl_enc_cfg;
 

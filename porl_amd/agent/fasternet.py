@@ -95,10 +95,15 @@ class FasterNet(nn.Module):
         # costmap geometry: the reference rasterises to 360 x 256 (util/costmap.py:7,12,24) and cannot do otherwise;
         # `angle_bins` / `dist_bins` (multiples of 4) parametrise it, e.g. the 84 x 84 image BASELINE config 5 names.
         # The state then carries angle_bins beams + the 2 goal coordinates.
-        # compute_dtype="bf16": the 1x1 / merge convolutions multiply bf16-rounded operands on the bf16 matrix pipe with
-        # fp32 accumulation (BASELINE config 5's wording).  The reference is fp32 everywhere; "fp32" is the parity path.
-        if compute_dtype not in ("fp32", "bf16"):
-            raise ValueError("compute_dtype must be 'fp32' or 'bf16'")
+        # compute_dtype="bf16" (BASELINE config 5's wording; the reference is fp32 everywhere): the backbone after the patch
+        # embedding keeps its activations in HBM as bf16 and runs the partial 3x3 conv, the MLP blocks (one kernel per pass
+        # over x: W1 -> BatchNorm -> ReLU -> W2 -> residual) and the 2x2s2 merge on the bf16 matrix pipe with fp32
+        # accumulation (csrc/encoder_bf16.hpp); BatchNorm statistics, the patch embedding's arithmetic and the pooled head
+        # stay fp32.  Shapes other than the reference architecture (embed 96, mlp_ratio 2, n_div 4) fall back to
+        # "bf16_operands": fp32 tensors in memory, operands rounded to bf16 on their way into LDS (round 2's mode, still
+        # selectable by name).  fp32 is the default and the parity path.
+        if compute_dtype not in ("fp32", "bf16", "bf16_operands"):
+            raise ValueError("compute_dtype must be 'fp32', 'bf16' or 'bf16_operands'")
         self.compute_dtype = compute_dtype
         if angle_bins is not None:
             self.ANGLE_BINS = int(angle_bins)
@@ -145,7 +150,7 @@ class FasterNet(nn.Module):
         self._cfg = N.EncCfg(self.ANGLE_BINS, self.DIST_BINS, int(embed_dim), int(depths[0]), int(depths[1]),
                              int(n_div), int(feature_dim), int(num_classes), int(max_batch), float(mlp_ratio),
                              float(self.patch_embed.norm.eps), float(self.patch_embed.norm.momentum),
-                             int(compute_dtype == "bf16"))
+                             {"fp32": 0, "bf16_operands": 1, "bf16": 2}[compute_dtype])
         h = C.c_void_p()
         N.check(self._lib.porl_enc_create(C.byref(self._cfg), C.byref(h)), "porl_enc_create")
         self._h = h

@@ -71,8 +71,18 @@ class GaussianPolicy(_EngineBacked):
         return DiagGaussian(mean, std)
 
     def act(self, obs, deterministic=False, enable_grad=False):
+        """policy.py:30-33.  enable_grad=True returns a mean that autograd can differentiate with respect to the
+        policy's parameters and `obs` (stand-alone forward through util/hip_mlp.py: same kernels, no engine state)."""
         if enable_grad:
-            raise NotImplementedError("autograd through the HIP forward is not provided")
+            from ..util.hip_mlp import mlp_forward
+            eng = self._engine
+            if eng is not None:
+                eng.join()                                        # a pipelined update may still be writing the parameters
+            with torch.enable_grad():
+                mean = mlp_forward(self.net, obs)
+                std = torch.exp(self.log_std.clamp(LOG_STD_MIN, LOG_STD_MAX))
+            dist = DiagGaussian(mean, std)
+            return dist.mean if deterministic else dist.mean + dist.stddev * torch.randn_like(dist.mean)
         dist = self(obs)
         return dist.mean if deterministic else dist.sample()
 
@@ -102,11 +112,17 @@ class BoundedGaussianPolicy(GaussianPolicy):
 
 
 class DeterministicPolicy(nn.Module):
-    """Parameter container only (unused; reference policy.py:62-73)."""
+    """Tanh-bounded deterministic policy (reference policy.py:62-73; unused by the training scripts): forward on the
+    device through util/hip_mlp.py (Linear/ReLU chain, tanh in the last product's epilogue), differentiable."""
 
     def __init__(self, obs_dim, act_dim, hidden_dim=256, n_hidden=2):
         super().__init__()
         self.net = mlp([obs_dim, *([hidden_dim] * n_hidden), act_dim], output_activation=nn.Tanh)
 
     def forward(self, obs):
-        raise NotImplementedError("DeterministicPolicy is not on the accelerated path")
+        from ..util.hip_mlp import mlp_forward
+        return mlp_forward(self.net, obs)
+
+    def act(self, obs, deterministic=False, enable_grad=False):
+        with torch.set_grad_enabled(enable_grad):
+            return self(obs)

@@ -55,7 +55,8 @@ class TwinV(_EngineBacked):
 
 
 class TwinQ(nn.Module):
-    """Parameter container only (unused by POR/SORL; reference value_functions.py:6-18)."""
+    """Twin Q(s, a) heads (reference value_functions.py:6-18; unused by POR / SORL).  `both` / `forward` run the two
+    Linear/ReLU chains on the device through the fp32-MFMA GEMM (util/hip_mlp.py), differentiable like any module."""
 
     def __init__(self, state_dim, action_dim, hidden_dim=256, n_hidden=2):
         super().__init__()
@@ -64,18 +65,22 @@ class TwinQ(nn.Module):
         self.q2 = mlp(dims, squeeze_output=True)
 
     def both(self, state, action):
-        raise NotImplementedError("TwinQ is not on the accelerated path (no caller in the reference)")
+        from ..util.hip_mlp import mlp_forward
+        sa = torch.cat([state, action], 1)
+        return mlp_forward(self.q1, sa), mlp_forward(self.q2, sa)
 
     def forward(self, state, action):
         return torch.min(*self.both(state, action))
 
 
 class ValueFunction(nn.Module):
-    """Parameter container only (unused by POR/SORL; reference value_functions.py:21-28)."""
+    """Single V(s) head (reference value_functions.py:21-28; unused by POR / SORL); forward on the device through
+    util/hip_mlp.py."""
 
     def __init__(self, state_dim, hidden_dim=256, n_hidden=2):
         super().__init__()
         self.v = mlp([state_dim, *([hidden_dim] * n_hidden), 1], squeeze_output=True)
 
     def forward(self, state):
-        raise NotImplementedError("ValueFunction is not on the accelerated path (no caller in the reference)")
+        from ..util.hip_mlp import mlp_forward
+        return mlp_forward(self.v, state)

@@ -181,6 +181,9 @@ __global__ __launch_bounds__(256) void patch_stats_kernel(const float* __restric
 
 // thread i of a block = (patch column i / (E/4), channel group i % (E/4)): consecutive lanes write consecutive
 // 16-byte pieces of the output rows
+// OUT_BF16: the normalised patch embedding leaves as bf16 (the encoder's bf16-activation mode, encoder_bf16.hpp); `out`
+// then points at a (rows, E) bf16 tensor.  The arithmetic up to the store is the fp32 path's.
+template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void patch_bn_kernel(const float* __restrict__ state, long state_rs, CostmapGeom g,
                                                        const float* __restrict__ w, int E, const float* __restrict__ alpha,
                                                        const float* __restrict__ beta, float* __restrict__ out) {
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256) void patch_bn_kernel(const float* __restrict__
   __syncthreads();
   patch_row_masks(state + b * state_rs, g, py, mask, t);
   __syncthreads();
-  float* orow = out + (b * Hp + py) * (long)Wp * E;
+  float* orow = out + (b * Hp + py) * (long)Wp * (OUT_BF16 ? E / 2 : E);      // bf16 rows are half as long
   for (int i = t; i < Wp * e4n; i += 256) {
     const int px = i / e4n, c = (i - px * e4n) << 2;
     const unsigned long long m = mask[px];
@@ -210,7 +213,14 @@ __global__ __launch_bounds__(256) void patch_bn_kernel(const float* __restrict__
       o.z = fmaf(patch_value(m, wl, E, c + 2), a4.z, o.z);
       o.w = fmaf(patch_value(m, wl, E, c + 3), a4.w, o.w);
     }
-    reinterpret_cast<float4*>(orow)[i] = o;
+    if constexpr (OUT_BF16) {
+      typedef __bf16 pb_bf16x4 __attribute__((ext_vector_type(4)));
+      pb_bf16x4 ob;
+      ob.x = (__bf16)o.x; ob.y = (__bf16)o.y; ob.z = (__bf16)o.z; ob.w = (__bf16)o.w;
+      reinterpret_cast<pb_bf16x4*>(orow)[i] = ob;
+    } else {
+      reinterpret_cast<float4*>(orow)[i] = o;
+    }
   }
 }
 

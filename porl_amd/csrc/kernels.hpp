@@ -914,6 +914,14 @@ struct CqlLossArgs {
   float* part_td; float* part_pen; // per block
   int B, A;
   float gamma, alpha, inv_batch, log_A;
+  // DQN variants (the arithmetic of qnet_fused.hpp:qf_loss_rows, so wide networks behave like narrow ones):
+  const float* Qon;                // Double DQN (ddqn_trainer.py:58-99): Q_online(s', .), bootstrap action = its first argmax;
+                                   // may alias dQ (a thread reads its row before it writes it); null = plain max
+  const float* is_w;               // (B,) per-sample loss weights, or null
+  const float* w_uniform;          // device scalar multiplying every sample's loss, or null
+  float* td_abs;                   // (B,) |Q(s)[a] - target|, or null
+  const float* next_mask;          // (B, A) 0/1: BCQ's allowed bootstrap actions (policy/bcq.py:59-74), or null
+  int td_off;                      // 1: no TD term (behaviour-policy pre-training, bcq.py:23-47)
 };
 
 __global__ __launch_bounds__(256) void cql_loss_kernel(const CqlLossArgs a) {
@@ -930,15 +938,36 @@ __global__ __launch_bounds__(256) void cql_loss_kernel(const CqlLossArgs a) {
     const float lse = mx + logf(se);
     const int act = (int)a.actions[b];
     const float qa = q[act];
-    const float y = a.rew[b] + a.gamma * mxn * (1.f - a.done[b]);
-    const float diff = qa - y;
-    td = diff * diff;
+    float qnext = mxn;
+    if (a.Qon) {                                  // Double DQN: the online network picks, the target network values
+      const float* qo = a.Qon + (size_t)b * a.ldq;
+      int am = 0;
+      float best = qo[0];
+      for (int j = 1; j < a.A; ++j) if (qo[j] > best) { best = qo[j]; am = j; }     // first maximum, like torch.argmax
+      qnext = qn[am];
+    }
+    if (a.next_mask) {
+      const float* mk = a.next_mask + (size_t)b * a.A;
+      int best = 0;
+      float bestv = qn[0] + (mk[0] - 1.f) * 1e10f;
+      for (int j = 1; j < a.A; ++j) {
+        const float v = qn[j] + (mk[j] - 1.f) * 1e10f;
+        if (v > bestv) { bestv = v; best = j; }
+      }
+      qnext = qn[best];
+    }
+    const float y = a.rew[b] + a.gamma * qnext * (1.f - a.done[b]);
+    const float diff = a.td_off ? 0.f : qa - y;
+    float wgt = a.is_w ? a.is_w[b] : 1.f;
+    if (a.w_uniform) wgt *= a.w_uniform[0];
+    td = wgt * (diff * diff);
     pen = lse - a.log_A - qa;
+    if (a.td_abs) a.td_abs[b] = fabsf(diff);
     float* dq = a.dQ + (size_t)b * a.ldq;
     const float ab = a.alpha * a.inv_batch;
     for (int j = 0; j < a.A; ++j) {
       float g = ab * expf(q[j] - lse);
-      if (j == act) g += 2.f * a.inv_batch * diff - ab;
+      if (j == act) g += 2.f * a.inv_batch * wgt * diff - ab;
       dq[j] = g;
     }
     for (int j = a.A; j < a.ldq; ++j) dq[j] = 0.f;
@@ -951,6 +980,25 @@ __global__ __launch_bounds__(256) void cql_loss_kernel(const CqlLossArgs a) {
     a.part_td[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     a.part_pen[blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   }
+}
+
+// Minibatch gather of the multi-launch Q-network path: rows idx[b] of the replay arrays -> the engine's staging buffers
+// (states / next states zero padded to ld columns).  grid (ceil(B * ld / 256)), the first B threads also move the
+// row's action, reward and done flag.
+struct QnetGatherArgs {
+  const float* states; const float* next_states; long s_rs, n_rs;
+  const int64_t* actions; const float* rew; const float* done; const int64_t* idx;
+  float* xs; float* xn; int64_t* act_out; float* rew_out; float* done_out;
+  int B, S, ld;
+};
+__global__ __launch_bounds__(256) void qnet_gather_kernel(const QnetGatherArgs a) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)a.B * a.ld) return;
+  const int b = (int)(i / a.ld), c = (int)(i - (long)b * a.ld);
+  const long row = a.idx ? a.idx[b] : (long)b;
+  a.xs[i] = c < a.S ? a.states[row * a.s_rs + c] : 0.f;
+  a.xn[i] = c < a.S ? a.next_states[row * a.n_rs + c] : 0.f;
+  if (c == 0) { a.act_out[b] = a.actions[row]; a.rew_out[b] = a.rew[row]; a.done_out[b] = a.done[row]; }
 }
 
 // stats[0] = loss, [1] = td, [2] = penalty (this rank's shares)

@@ -133,6 +133,7 @@ int g_skinny_pipelined = 0;
 inline int skinny_mask() { return g_short_blocks ? g_skinny_pipelined : g_skinny; }
 int g_dw0_slabs = 16;        // porl_tune_set("dw0_slabs", n <= SK_MAX): slabs of the skinny dW0 kernel (A/B: fewer slabs = fewer partial bytes, fewer blocks)
 int g_iql_fold = 1;          // porl_tune_set("iql_fold", 0): porl_iql_step keeps the slab combines as launches of their own (A/B)
+int g_enc_bf16_operands_only = 0;   // porl_tune_set("enc_bf16_operands_only", 1): compute_dtype="bf16" runs round 2's bf16-OPERAND mode (fp32 tensors in memory) instead of encoder_bf16.hpp (A/B)
 int g_enc_bn_sweep = 0;      // porl_tune_set("enc_bn_sweep", 1): BatchNorm + ReLU of the MLP blocks as a separate sweep (cross-check)
 int g_enc_dense_patch = 0;   // porl_tune_set("enc_dense_patch", 1): rasterise + dense patch embedding (cross-check)
 int g_qnet_fused = 1;     // porl_tune_set("qnet_fused", 0) forces the multi-launch CQL path (A/B measurements)
@@ -1483,6 +1484,7 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "enc_dense_patch")) { g_enc_dense_patch = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_s2d")) { g_enc_s2d = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_bn_sweep")) { g_enc_bn_sweep = value != 0; return PORL_OK; }
+  if (!strcmp(key, "enc_bf16_operands_only")) { g_enc_bf16_operands_only = value != 0; return PORL_OK; }
   if (!strcmp(key, "iql_fold")) { g_iql_fold = value != 0; return PORL_OK; }
   if (!strcmp(key, "skinny")) { g_skinny = value == 1 ? 7 : value; return PORL_OK; }
   if (!strcmp(key, "skinny_pipelined")) { g_skinny_pipelined = value == 1 ? 7 : value; return PORL_OK; }
@@ -1976,15 +1978,25 @@ static int qnet_backward_chain(porl_qnet* h, float* dz, int B, hipStream_t s) {
   return PORL_OK;
 }
 
+// Multi-launch gradient of the loaded minibatch (any layer widths): forwards through the grouped GEMM, loss head with
+// the optional DQN variants, backward chain.  `var` may be null (plain CQL / DQN).
+static int qnet_general_backward(porl_qnet* h, const porl_qnet_hyper* hp, const porl_qnet_variant* var, hipStream_t s);
+
 int porl_qnet_cql_backward(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
   PORL_TRY(qnet_ready(h, true)); DevGuard _dg(h->device);
   if (!hp) PORL_FAIL(PORL_ERR_INVALID, "null hyper-parameters");
   hipStream_t s = (hipStream_t)stream;
-  const int B = h->batch, L = h->cfg.n_hidden, A = h->cfg.n_actions;
+  const int B = h->batch;
   float* W = h->buf.workspace;
   if (h->fused_ok && g_qnet_fused)
     return qnet_fused_backward(h, hp, B, W + h->ws.xs, h->Sp, W + h->ws.xn, h->Sp,
                                reinterpret_cast<const int64_t*>(W + h->ws.actions), W + h->ws.rew, W + h->ws.done, nullptr, s);
+  return qnet_general_backward(h, hp, nullptr, s);
+}
+
+static int qnet_general_backward(porl_qnet* h, const porl_qnet_hyper* hp, const porl_qnet_variant* var, hipStream_t s) {
+  const int B = h->batch, L = h->cfg.n_hidden, A = h->cfg.n_actions;
+  float* W = h->buf.workspace;
   // forward: target net on s' (activations ping-pong in tmp), online net on s (activations kept)
   float* dst[2][PORL_MAX_HIDDEN + 1];
   for (int l = 0; l <= L; ++l) { dst[0][l] = W + h->ws.tmp[l & 1]; dst[1][l] = W + h->ws.act[l]; }
@@ -1994,9 +2006,22 @@ int porl_qnet_cql_backward(porl_qnet* h, const porl_qnet_hyper* hp, void* stream
   float* Qn = dst[0][L];
   float* Q = dst[1][L];
   float* dz = W + h->ws.dz[L & 1];
+  const float* Qon = nullptr;
+  if (var && var->double_dqn) {
+    // Double DQN: the online network on s' as well; its activations ping-pong through the two dZ buffers (free until the
+    // loss head writes dL/dQ), so Q_online(s') ends in the buffer dL/dQ goes to — a row is read before it is written
+    float* dst2[1][PORL_MAX_HIDDEN + 1];
+    for (int l = 0; l <= L; ++l) dst2[0][l] = W + h->ws.dz[l & 1];
+    const float* p2[1] = {h->buf.params};
+    const float* in2[1] = {W + h->ws.xn};
+    PORL_TRY(qnet_forward(h, 1, p2, in2, dst2, B, s));
+    Qon = dst2[0][L];
+  }
   const int nblk = cdiv(B, 256);
   {
     CqlLossArgs a{};
+    a.Qon = Qon;
+    if (var) { a.is_w = var->is_weights; a.w_uniform = var->uniform_weight; a.td_abs = var->td_abs; a.next_mask = var->next_mask; a.td_off = var->td_off; }
     a.Q = Q; a.Qn = Qn; a.ldq = h->ld[L];
     a.actions = reinterpret_cast<const int64_t*>(W + h->ws.actions); a.rew = W + h->ws.rew; a.done = W + h->ws.done;
     a.dQ = dz; a.part_td = W + h->ws.part_td; a.part_pen = W + h->ws.part_pen;
@@ -2124,6 +2149,27 @@ int porl_qnet_learn(porl_qnet* h, const porl_qnet_hyper* hp, void* stream) {
   return porl_qnet_apply(h, hp, stream);
 }
 
+// learn() on rows idx[b] of the replay arrays for networks the one-launch kernel does not cover: gather into the staging
+// buffers (one launch), multi-launch gradient with the variant's loss head, Adam.  Same arithmetic per element as the
+// one-launch kernel's loss stage; sums run in the grouped GEMM's order instead of per 32-row block.
+static int qnet_general_learn(porl_qnet* h, const porl_qnet_hyper* hp, const porl_qnet_variant* var, int batch,
+                              const float* states, int64_t s_rs, const float* next_states, int64_t n_rs,
+                              const int64_t* actions, const float* rewards, const float* dones, const int64_t* idx,
+                              hipStream_t s) {
+  float* W = h->buf.workspace;
+  QnetGatherArgs a{};
+  a.states = states; a.next_states = next_states; a.s_rs = (long)s_rs; a.n_rs = (long)n_rs;
+  a.actions = actions; a.rew = rewards; a.done = dones; a.idx = idx;
+  a.xs = W + h->ws.xs; a.xn = W + h->ws.xn; a.act_out = reinterpret_cast<int64_t*>(W + h->ws.actions);
+  a.rew_out = W + h->ws.rew; a.done_out = W + h->ws.done;
+  a.B = batch; a.S = h->cfg.state_dim; a.ld = h->Sp;
+  hipLaunchKernelGGL(qnet_gather_kernel, dim3((unsigned)(((long)batch * h->Sp + 255) / 256)), dim3(256), 0, s, a);
+  PORL_HIP(hipGetLastError());
+  h->batch = batch;
+  PORL_TRY(qnet_general_backward(h, hp, var, s));
+  return porl_qnet_apply(h, hp, (void*)s);
+}
+
 int porl_qnet_learn_indexed(porl_qnet* h, const float* states, int64_t s_rs, const int64_t* actions, const float* rewards,
                             const float* next_states, int64_t n_rs, const float* dones, const int64_t* idx, int32_t batch,
                             const porl_qnet_hyper* hp, void* stream) {
@@ -2131,8 +2177,7 @@ int porl_qnet_learn_indexed(porl_qnet* h, const float* states, int64_t s_rs, con
   if (!hp || !states || !actions || !rewards || !next_states || !dones) PORL_FAIL(PORL_ERR_INVALID, "null argument");
   if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
   if (!h->fused_ok || !g_qnet_fused)
-    PORL_FAIL(PORL_ERR_UNSUPPORTED, "the one-launch path needs every layer <= %d wide and <= %d Linear layers; gather the "
-              "minibatch and use porl_qnet_load_batch + porl_qnet_learn", QF_MAX_W, QF_MAX_LIN);
+    return qnet_general_learn(h, hp, nullptr, batch, states, s_rs, next_states, n_rs, actions, rewards, dones, idx, (hipStream_t)stream);
   return qnet_fused_backward(h, hp, batch, states, s_rs, next_states, n_rs, actions, rewards, dones, idx,
                              (hipStream_t)stream, true);
 }
@@ -2161,7 +2206,8 @@ int porl_qnet_learn_variant(porl_qnet* h, const float* states, int64_t s_rs, con
   PORL_TRY(qnet_ready(h, false)); DevGuard _dg(h->device);
   if (!hp || !states || !actions || !rewards || !next_states || !dones || !variant) PORL_FAIL(PORL_ERR_INVALID, "null argument");
   if (batch < 1 || batch > h->cfg.max_batch) PORL_FAIL(PORL_ERR_INVALID, "batch %d outside [1,%d]", batch, h->cfg.max_batch);
-  if (!h->fused_ok || !g_qnet_fused) PORL_FAIL(PORL_ERR_UNSUPPORTED, "the DQN variants run on the one-launch kernel only");
+  if (!h->fused_ok || !g_qnet_fused)      // wide networks (a layer > 128 wide, > 5 Linear layers): the multi-launch path
+    return qnet_general_learn(h, hp, variant, batch, states, s_rs, next_states, n_rs, actions, rewards, dones, idx, (hipStream_t)stream);
   return qnet_fused_backward(h, hp, batch, states, s_rs, next_states, n_rs, actions, rewards, dones, idx,
                              (hipStream_t)stream, true, variant);
 }

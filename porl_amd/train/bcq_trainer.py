@@ -19,8 +19,6 @@ class BCQTrainer(DQNTrainer):
         super().__init__(state_size, action_size, gamma, epsilon, epsilon_min, epsilon_decay, update_target_freq, device,
                          log_dir=log_dir, network=network, **kw)
         self.num_epochs, self.threshold = num_epochs, threshold
-        if not self._engine.fused:
-            raise NotImplementedError("BCQTrainer needs a Q-network the one-launch step kernel covers (layers <= 128 wide)")
         # bcq_trainer.py:59-62 (constructed after the Q-networks: same RNG consumption order)
         self.behavior_policy = behavior_policy(state_size, action_size)
         hidden = self.behavior_policy._spec[2]

@@ -108,8 +108,10 @@ class QnetEngine:
     def learn(self, hp): N.check(self._lib.porl_qnet_learn(self._h, C.byref(hp), N.current_stream_ptr(self.device)), "porl_qnet_learn")
 
     def learn_indexed(self, hp, states, actions, rewards, next_states, dones, idx, variant=None):
-        """learn() on rows `idx` (int64, device) of device-resident replay arrays, gathered inside the step kernel.
-        Raises NativeError(PORL_ERR_UNSUPPORTED) for networks the one-launch kernel does not cover."""
+        """learn() on rows `idx` (int64, device) of device-resident replay arrays: gathered inside the one-launch step
+        kernel, or — networks with a layer wider than 128 or more than five Linear layers — by one gather launch in
+        front of the multi-launch path (same loss arithmetic, incl. the Double-DQN / importance-weight / BCQ-mask
+        variants)."""
         self._ensure_bound()
         B = idx.numel()
         if B > self.cfg.max_batch:
@@ -216,11 +218,13 @@ class CQLTrainer:
         self.gamma, self.epsilon, self.epsilon_min, self.epsilon_decay = gamma, epsilon, epsilon_min, epsilon_decay
         self.learning_rate, self.update_target_freq = learning_rate, update_target_freq
         self.num_epochs, self.threshold, self.alpha = num_epochs, threshold, alpha
-        if network is not QNetwork:
-            raise NotImplementedError("only QNetwork is on the accelerated path")
-        # same construction order / RNG consumption as dqn_trainer.py:66-70
+        # same construction order / RNG consumption as dqn_trainer.py:66-70; `network` is any callable (state_size,
+        # action_size) -> QNetwork, e.g. `lambda s, a: QNetwork(s, a, [256, 256])` for other hidden sizes
         self.q_network = network(state_size, action_size)
         self.target_network = network(state_size, action_size)
+        if not isinstance(self.q_network, QNetwork) or not isinstance(self.target_network, QNetwork):
+            raise NotImplementedError("only QNetwork (a plain Linear/ReLU chain) is on the accelerated path; "
+                                      "DuelingQNetwork (q_network.py:33-68) is not provided")
         hidden = self.q_network._spec[2]
         self._engine = QnetEngine(state_size, action_size, hidden, max(max_batch, batch_size), self.device)
         with torch.no_grad():

@@ -22,8 +22,6 @@ class PERTrainer(CQLTrainer):
         super().__init__(state_size, action_size, gamma, epsilon, epsilon_min, epsilon_decay, update_target_freq, device,
                          log_dir=log_dir, num_epochs=num_epochs, threshold=threshold, alpha=0,
                          learning_rate=learning_rate, batch_size=batch_size, max_batch=max_batch, **kw)
-        if not self._engine.fused:
-            raise NotImplementedError("PERTrainer needs a Q-network the one-launch step kernel covers (layers <= 128 wide)")
         # dqn_per_trainer.py:62-65
         self.memory = PrioritizedReplayBuffer(capacity, alpha=0.6, beta_start=0.4, beta_frames=100000,
                                               state_shape=(state_size,), device=self.device)

@@ -27,8 +27,6 @@ class DDQNTrainer(DQNTrainer):
     def __init__(self, *args, num_epochs=1000, threshold=0.1, **kw):
         super().__init__(*args, **kw)
         self.num_epochs, self.threshold = num_epochs, threshold
-        if not self._engine.fused:
-            raise NotImplementedError("DDQNTrainer needs a Q-network the one-launch step kernel covers (layers <= 128 wide)")
 
     def learn_on(self, states, actions, rewards, next_states, dones):
         """ddqn_trainer.py:58-99 on an explicit minibatch (device tensors)."""

@@ -233,8 +233,20 @@ def test_wide_networks_keep_the_multi_launch_path():
     assert not QnetEngine(60, 10, (64, 256, 64), 64, DEV).fused
 
 
+@pytest.fixture
+def qnet_path(request):
+    """"fused" = the one-launch step kernel; "general" = the multi-launch path every network wider than 128 takes
+    (gather launch + grouped GEMMs + the variant-aware loss head), forced here on the SAME small networks so that it is
+    pinned by the same reference goldens."""
+    from porl_amd import engine as E
+    E.tune_set("qnet_fused", 1 if request.param == "fused" else 0)
+    yield request.param
+    E.tune_set("qnet_fused", 1)
+
+
+@pytest.mark.parametrize("qnet_path", ["fused", "general"], indirect=True)
 @pytest.mark.parametrize("name", ["dqn_s10_a6", "ddqn_s10_a6"])
-def test_dqn_and_double_dqn_learn_match_reference_golden(name):
+def test_dqn_and_double_dqn_learn_match_reference_golden(name, qnet_path):
     """DQNTrainer.learn (dqn_trainer.py:93-118) and DDQNTrainer.learn (ddqn_trainer.py:58-99): five steps under the
     reference's numpy index stream, from the reference's initial online/target parameters."""
     from porl_amd.train.dqn_trainer import DDQNTrainer, DQNTrainer
@@ -242,6 +254,7 @@ def test_dqn_and_double_dqn_learn_match_reference_golden(name):
     S, A, B, K, N, seed_model, seed_data, seed_np, double = (int(v) for v in z["meta"])
     cls = DDQNTrainer if double else DQNTrainer
     t = cls(S, A, float(z["gamma"]), device=DEV, batch_size=B)
+    assert t._engine.fused == (qnet_path == "fused")
     t.q_network.load_state_dict({k: torch.from_numpy(v) for k, v in sub(z, "init/").items()})
     t.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in sub(z, "init_target/").items()})
     st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=seed_data)
@@ -256,7 +269,48 @@ def test_dqn_and_double_dqn_learn_match_reference_golden(name):
         np.testing.assert_allclose(got[k], v, atol=1e-5, err_msg=k)
 
 
-def test_bcq_pretrain_and_learn_match_reference_golden():
+def test_double_dqn_on_a_wide_network_equals_the_oracle_step():
+    """network_hidden_sizes beyond the one-launch kernel's 128 columns (dqn_trainer.py:66-69 lets the caller pick any):
+    DDQNTrainer takes the multi-launch path by itself; one step against a direct fp64 evaluation of ddqn_trainer.py:58-99
+    from the same parameters (loss and the updated output-layer bias, whose gradient is the column sum of dL/dQ)."""
+    from porl_amd.net.q_network import QNetwork
+    from porl_amd.train.dqn_trainer import DDQNTrainer
+    S, A, B = 12, 7, 96
+    torch.manual_seed(3)
+    t = DDQNTrainer(S, A, 0.97, device=DEV, batch_size=B, network=lambda s, a: QNetwork(s, a, [48, 200, 160]))
+    assert not t._engine.fused
+    g = torch.Generator().manual_seed(5)
+    st, ns = torch.randn(B, S, generator=g), torch.randn(B, S, generator=g)
+    ac = torch.randint(0, A, (B,), generator=g)
+    rw, dn = torch.randn(B, generator=g), (torch.rand(B, generator=g) < 0.2).float()
+    P = {k: v.detach().cpu().double() for k, v in t.q_network.state_dict().items()}
+    T = {k: v.detach().cpu().double() for k, v in t.target_network.state_dict().items()}
+
+    def fwd(p, x):
+        h = x.double()
+        keys = sorted({k.rsplit(".", 1)[0] for k in p}, key=lambda s: int(s.split(".")[-1]))
+        for i, k in enumerate(keys):
+            h = h @ p[k + ".weight"].T + p[k + ".bias"]
+            if i < len(keys) - 1:
+                h = torch.relu(h)
+        return h
+    q, qn_t, qn_o = fwd(P, st), fwd(T, ns), fwd(P, ns)
+    qa = q[torch.arange(B), ac]
+    y = rw.double() + 0.97 * qn_t[torch.arange(B), qn_o.argmax(1)] * (1 - dn.double())
+    want = float(((qa - y) ** 2).mean())
+    loss = t.learn_on(st.to(DEV), ac.to(DEV), rw.to(DEV), ns.to(DEV), dn.to(DEV))
+    np.testing.assert_allclose(loss, want, rtol=2e-5)
+    # first Adam step: every parameter moves by lr * sign(grad) (up to eps); check the sign pattern of the output bias
+    gb = torch.zeros(A, dtype=torch.float64).index_add_(0, ac, 2 * (qa - y) / B)
+    last = sorted(P, key=lambda k: int(k.split(".")[-2]))[-1].rsplit(".", 1)[0] + ".bias"
+    moved = t.q_network.state_dict()[last].cpu().double() - P[last]
+    big = gb.abs() > 1e-6
+    assert torch.equal(torch.sign(moved[big]), -torch.sign(gb[big]))
+    np.testing.assert_allclose(moved[big].abs().numpy(), 5e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("qnet_path", ["fused", "general"], indirect=True)
+def test_bcq_pretrain_and_learn_match_reference_golden(qnet_path):
     """Discrete BCQ (src/porl/policy/bcq.py): six cross-entropy epochs of the behaviour policy (:23-47), then five
     bcq_learn steps (:50-86) whose bootstrap action is the masked argmax of the target network — under the reference's
     numpy index stream, from the reference's initial Q / target / behaviour parameters."""

@@ -347,13 +347,16 @@ def test_por_with_encoder_backbone_matches_reference_golden():
         agent.update_from_replay(None, B)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "bf16_operands"])
 @pytest.mark.parametrize("n_ang,n_dist", [(360, 256), (84, 84)])
-def test_bf16_operand_mode_stays_close_to_the_fp32_path(n_ang, n_dist):
-    """compute_dtype="bf16" (BASELINE config 5's wording; the reference has no bf16 path): the 1x1 / merge
-    convolutions round their operands to bf16 (8 significant bits) and accumulate in fp32.  Tolerance defined by the
-    build and stated here: features within 3e-2 of the largest fp32 feature magnitude (measured ~5e-3), running
-    statistics within 1e-2 relative, against the fp32 path on identical weights, inputs and DropPath masks — the fp32
-    path itself is pinned to the reference at 2e-5."""
+def test_bf16_modes_stay_close_to_the_fp32_path(n_ang, n_dist, mode):
+    """compute_dtype="bf16" (BASELINE config 5's wording; the reference has no bf16 path): bf16 activations in HBM behind
+    the patch embedding, partial conv / fused MLP blocks / merge on the bf16 matrix pipe with fp32 accumulation
+    (csrc/encoder_bf16.hpp); "bf16_operands" (round 2's mode): fp32 tensors in memory, operands of the 1x1 / merge
+    convolutions rounded to bf16 on their way into LDS.  Tolerance defined by the build and stated here: features within
+    3e-2 of the largest fp32 feature magnitude, running statistics within 1e-2 relative, against the fp32 path on
+    identical weights, inputs and DropPath masks (a dropped sample included) — the fp32 path itself is pinned to the
+    reference at 2e-5."""
     from porl_amd.agent.fasternet import FasterNet
     B = 6
     rng = np.random.default_rng(3)
@@ -361,16 +364,23 @@ def test_bf16_operand_mode_stays_close_to_the_fp32_path(n_ang, n_dist):
     st[:, :n_ang] = rng.uniform(0.2, 3.9, size=(B, n_ang))
     st[:, n_ang:] = rng.uniform(-3, 3, size=(B, 2))
     outs = {}
-    for dt in ("fp32", "bf16"):
+    scale = torch.ones(3, B)
+    scale[1, 2] = 0.0
+    scale[2, 4] = 1 / 0.9
+    for dt in ("fp32", mode):
         torch.manual_seed(5)
         m = FasterNet(3, 256, max_batch=8, angle_bins=n_ang, dist_bins=n_dist, compute_dtype=dt).to(DEV)
         m.train()
-        tr = m(torch.from_numpy(st.copy()).to(DEV), drop_scale=torch.ones(3, B)).cpu().numpy()
+        tr = m(torch.from_numpy(st.copy()).to(DEV), drop_scale=scale).cpu().numpy()
         m.eval()
         ev = m(torch.from_numpy(st.copy()).to(DEV)).cpu().numpy()
-        outs[dt] = (tr, ev, {k: v.cpu().numpy() for k, v in m.state_dict().items() if "running_var" in k})
+        outs[dt] = (tr, ev, {k: v.cpu().numpy() for k, v in m.state_dict().items() if "running" in k})
     for i in (0, 1):
-        err = rel_err(outs["bf16"][i], outs["fp32"][i].astype(np.float64))
+        err = rel_err(outs[mode][i], outs["fp32"][i].astype(np.float64))
         assert 0 < err < 3e-2, err                       # > 0: the bf16 kernels really ran
     for k, v in outs["fp32"][2].items():
-        assert rel_err(outs["bf16"][2][k], v.astype(np.float64)) < 1e-2, k
+        if "running_var" in k:
+            assert rel_err(outs[mode][2][k], v.astype(np.float64)) < 1e-2, k
+        elif "running_mean" in k:                        # channel means sit near zero: on the scale of the channel's deviation
+            sd = np.sqrt(outs["fp32"][2][k.replace("running_mean", "running_var")].max() / 0.1)
+            assert np.abs(outs[mode][2][k] - v).max() < 2e-2 * sd, k

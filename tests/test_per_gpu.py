@@ -73,9 +73,19 @@ def test_tree_invariants_at_scale():
     assert abs(hits[:10].sum() - expect_heavy) < 6 * np.sqrt(expect_heavy)
 
 
-def test_per_trainer_learn_matches_reference_golden():
+@pytest.fixture
+def qnet_path(request):
+    from porl_amd import engine as E
+    E.tune_set("qnet_fused", 1 if request.param == "fused" else 0)
+    yield request.param
+    E.tune_set("qnet_fused", 1)
+
+
+@pytest.mark.parametrize("qnet_path", ["fused", "general"], indirect=True)
+def test_per_trainer_learn_matches_reference_golden(qnet_path):
     """PERTrainer.learn (dqn_per_trainer.py:67-123): Double-DQN target, the reference's (B,1)x(B,) weighted loss,
-    Adam, priority write-back — four steps under the same `random` stream."""
+    Adam, priority write-back — four steps under the same `random` stream; on the one-launch kernel and on the
+    multi-launch path wide networks take."""
     from conftest import sub
     from porl_amd.train.dqn_per_trainer import PERTrainer
     from porl_amd.util.synth import make_discrete_transitions

@@ -347,7 +347,21 @@ def test_por_global_batch_of_config4_on_one_gpu():
     _cmp_params_robust(_np_sd(agent), o.P, max_tol=2.1e-4)
 
 
-def test_pipelined_updates_are_bit_identical_to_back_to_back_updates():
+@pytest.fixture(params=[0, 7], ids=["gemm-path", "skinny-path"])
+def same_kernels_in_both_modes(request):
+    """The pipelined update and the one-stream update pick their <= 64-wide products' kernels separately (csrc: g_skinny /
+    g_skinny_pipelined — by default skinny.hpp on one stream, the grouped GEMM in the pipelined update, where it measured
+    faster).  "Pipelining only reorders" is a statement about equal kernels, so these tests pin one selection for both
+    modes — each of the two; across selections results agree to rounding (test_skinny_kernels_agree_...)."""
+    from porl_amd import engine as E
+    E.tune_set("skinny", request.param)
+    E.tune_set("skinny_pipelined", request.param)
+    yield request.param
+    E.tune_set("skinny", 7)
+    E.tune_set("skinny_pipelined", 0)
+
+
+def test_pipelined_updates_are_bit_identical_to_back_to_back_updates(same_kernels_in_both_modes):
     """async_losses=True issues the policy phase of update t on the engine's side stream and lets update t+1's value
     phase run beside it (agent/_iql.py).  Same kernels on the same data in the same order per buffer: every loss,
     parameter and Adam moment must equal the single-stream run bit for bit; state read right after an update
@@ -377,7 +391,7 @@ def test_pipelined_updates_are_bit_identical_to_back_to_back_updates():
 
 
 @pytest.mark.parametrize("sync,ln", [("signal", False), ("event", False), ("signal", True), ("signal/phase-calls", False)])
-def test_pipelined_updates_at_the_headline_size_are_bit_identical(sync, ln, monkeypatch):
+def test_pipelined_updates_at_the_headline_size_are_bit_identical(sync, ln, monkeypatch, same_kernels_in_both_modes):
     """The same property at BASELINE config 2 (H = 1024, B = 1024, device sampler), where the two streams really
     overlap: 64x64 short blocks, the value phase's 1 024-block launches at two blocks per CU, three staging slots, the
     streams ordered by signal counters (or events).  40 pipelined updates against 40 one-stream updates: every
