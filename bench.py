@@ -471,7 +471,7 @@ def main():
                          "value_functions.py:32); with --batch for the small-network figures of DESIGN.md §7")
     ap.add_argument("--angle-bins", type=int, default=360, help="sorl_enc: costmap rows (360 = the reference's image)")
     ap.add_argument("--dist-bins", type=int, default=256, help="sorl_enc: costmap columns")
-    ap.add_argument("--enc-dtype", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--enc-dtype", default="fp32", choices=["fp32", "bf16", "bf16_operands"],
                     help="sorl_enc: operand type of the encoder's 1x1 / merge convolutions (fp32 = reference parity)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

@@ -56,6 +56,7 @@ __global__ void pack_pconv_bf16_kernel(const float* __restrict__ src, __bf16* __
 struct PconvBf16Args {
   const __bf16* x; __bf16* yc; const __bf16* w;   // w: pack_pconv_bf16_kernel's image
   int ldx, Hh, Ww, tiles_per_sample, nr_max;
+  int tiles_total, tiles_per_block;              // a block walks tiles_per_block consecutive tiles with the weight parked once
 };
 
 template <int CP, int CPP, int CPN, int POS>
@@ -66,46 +67,52 @@ __global__ __launch_bounds__(256) void pconv_bf16_kernel(const PconvBf16Args a) 
   __bf16* Wl = reinterpret_cast<__bf16*>(pcb_lds);                 // [9][CPN][XS]
   __bf16* X = Wl + 9 * CPN * XS;                                  // [nr][Ww + 2][XS]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, kh = lane >> 5;
-  const int b = blockIdx.x / a.tiles_per_sample, tile = blockIdx.x - b * a.tiles_per_sample;
-  const int P = a.Hh * a.Ww, p0 = tile * POS, p1 = min(P, p0 + POS) - 1;
-  const int y_lo = p0 / a.Ww - 1, nr = p1 / a.Ww + 1 - y_lo + 1, WW2 = a.Ww + 2;
-  // weights: linear 16-byte copy
+  const int P = a.Hh * a.Ww, WW2 = a.Ww + 2;
+  const int mt = wave % MT, nt = wave / MT;
+  // weights: linear 16-byte copy, once per block
   for (int i = t; i < 9 * CPN * XS / 8; i += 256)
     reinterpret_cast<u32x4*>(Wl)[i] = reinterpret_cast<const u32x4*>(a.w)[i];
-  // input rows with halo; units of 8 channels
-  for (int i = t; i < nr * WW2 * U; i += 256) {
-    const int pix = i / U, u = i - pix * U, ry = pix / WW2, rx = pix - ry * WW2;
-    const int yy = y_lo + ry, xx = rx - 1;
-    const bool ok = yy >= 0 && yy < a.Hh && xx >= 0 && xx < a.Ww && u * 8 < CP;
-    const u32x4 v = ld16_or_zero(a.x, (((long)b * a.Hh + yy) * a.Ww + xx) * a.ldx + u * 8, ok);
-    *reinterpret_cast<u32x4*>(X + pix * XS + u * 8) = v;
-  }
-  __syncthreads();
-  const int mt = wave % MT, nt = wave / MT;
-  const int p = p0 + 32 * mt + li;
-  const int pc = p < P ? p : p0;                                   // lanes past the sample compute a valid pixel, unused
-  const int yy = pc / a.Ww, xx = pc - yy * a.Ww;
-  const __bf16* xa = X + ((yy - y_lo) * WW2 + xx + 1) * XS + kh * 8;
-  const __bf16* wb = Wl + (32 * nt + li) * XS + kh * 8;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int off = ((tap / 3 - 1) * WW2 + (tap % 3 - 1)) * XS;
-#pragma unroll
-    for (int ks = 0; ks < CPP / 16; ++ks) {
-      const bf16x8 fa = *reinterpret_cast<const bf16x8*>(xa + off + ks * 16);
-      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(wb + tap * CPN * XS + ks * 16);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+  for (int k = 0; k < a.tiles_per_block; ++k) {
+    const int gt = blockIdx.x * a.tiles_per_block + k;
+    if (gt >= a.tiles_total) break;                                // block-uniform
+    const int b = gt / a.tiles_per_sample, tile = gt - b * a.tiles_per_sample;
+    const int p0 = tile * POS, p1 = min(P, p0 + POS) - 1;
+    const int y_lo = p0 / a.Ww - 1, nr = p1 / a.Ww + 1 - y_lo + 1;
+    if (k) __syncthreads();                                        // the previous tile's fragments have been read
+    // input rows with halo; units of 8 channels
+    for (int i = t; i < nr * WW2 * U; i += 256) {
+      const int pix = i / U, u = i - pix * U, ry = pix / WW2, rx = pix - ry * WW2;
+      const int yy = y_lo + ry, xx = rx - 1;
+      const bool ok = yy >= 0 && yy < a.Hh && xx >= 0 && xx < a.Ww && u * 8 < CP;
+      const u32x4 v = ld16_or_zero(a.x, (((long)b * a.Hh + yy) * a.Ww + xx) * a.ldx + u * 8, ok);
+      *reinterpret_cast<u32x4*>(X + pix * XS + u * 8) = v;
     }
-  }
-  const int oc = 32 * nt + li;
-  if (oc < CP) {
+    __syncthreads();
+    const int p = p0 + 32 * mt + li;
+    const int pc = p < P ? p : p0;                                 // lanes past the sample compute a valid pixel, unused
+    const int yy = pc / a.Ww, xx = pc - yy * a.Ww;
+    const __bf16* xa = X + ((yy - y_lo) * WW2 + xx + 1) * XS + kh * 8;
+    const __bf16* wb = Wl + (32 * nt + li) * XS + kh * 8;
+    f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int pos = p0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (pos < P) a.yc[((long)b * P + pos) * CP + oc] = (__bf16)acc[r];
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int off = ((tap / 3 - 1) * WW2 + (tap % 3 - 1)) * XS;
+#pragma unroll
+      for (int ks = 0; ks < CPP / 16; ++ks) {
+        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(xa + off + ks * 16);
+        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(wb + tap * CPN * XS + ks * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+      }
+    }
+    const int oc = 32 * nt + li;
+    if (oc < CP) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pos = p0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (pos < P) a.yc[((long)b * P + pos) * CP + oc] = (__bf16)acc[r];
+      }
     }
   }
 }
@@ -116,7 +123,8 @@ __global__ __launch_bounds__(256) void pconv_bf16_kernel(const PconvBf16Args a) 
 // chunk (64 columns of every row) are requested into registers one chunk ahead and parked in LDS between two
 // barriers.  Wave w owns rows 32 w .. 32 w + 31 of the tile for BOTH products, so the hidden chunk goes through LDS
 // wave-locally (written and read by the same wave: no block barrier).
-//   PASS 1: cstat[(row / 32), 0, j] = sum over the 32 rows of h[., j], [.., 1, j] = sum of squares   (GemmProb::cstat's format)
+//   PASS 1: cstat[tile, 0, j] = sum over the tile's 128 rows of h[., j], [tile, 1, j] = sum of squares   (GemmProb::cstat's
+//           format with one entry per 128 rows: colstats_from_blocks_kernel only adds the entries up)
 //   PASS 2: out = x + rscale[row / rs_rows] * (relu(h * alpha + beta) W2^T), bf16, in place over x
 // ---------------------------------------------------------------------------------------------------------------------
 struct EncMlpArgs {
@@ -139,6 +147,8 @@ __global__ __launch_bounds__(256) void enc_mlp_bf16_kernel(const EncMlpArgs a) {
   __bf16* W2c = Hc + ROWS * SH;                                  // [DIM][SH]      (PASS 2)
   __bf16* R = W2c + DIM * SH;                                    // [ROWS][CP]     (PASS 2: residual of the conv'd channels)
   float* ab = reinterpret_cast<float*>(R + ROWS * CP);           // [2][HID]       (PASS 2)
+  float* rsl = ab + 2 * HID;                                     // [ROWS]         (PASS 2: DropPath factor of each row)
+  float* st = reinterpret_cast<float*>(W1c + HC * SA);           // [4][2][HC]     (PASS 1: the four waves' column sums)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, kh = lane >> 5;
   const long r0 = (long)blockIdx.x * ROWS;
 
@@ -185,6 +195,8 @@ __global__ __launch_bounds__(256) void enc_mlp_bf16_kernel(const EncMlpArgs a) {
       *reinterpret_cast<u32x4*>(R + row * CP + u * 8) = ld16_or_zero(a.x, (r0 + row) * DIM + u * 8, r0 + row < a.rows);
     }
     for (int i = t; i < HID; i += 256) { ab[i] = a.alpha[i]; ab[HID + i] = a.beta[i]; }
+    // one (64-bit) division per row here instead of one per accumulator element in the epilogue
+    if (t < ROWS) rsl[t] = (a.rscale && r0 + t < a.rows) ? a.rscale[(r0 + t) / a.rs_rows] : 1.f;
   }
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -228,12 +240,15 @@ __global__ __launch_bounds__(256) void enc_mlp_bf16_kernel(const EncMlpArgs a) {
         for (int r = 0; r < 16; ++r) { cs += acc1[j][r]; cq = fmaf(acc1[j][r], acc1[j][r], cq); }
         cs += __shfl_xor(cs, 32);
         cq += __shfl_xor(cq, 32);
-        if (kh == 0 && r0 + 32 * wave < a.rows) {
-          float* o = a.cstat + ((r0 >> 5) + wave) * 2 * HID + c * HC + 32 * j + li;
-          o[0] = cs;
-          o[HID] = cq;
-        }
+        if (kh == 0) { st[(wave * 2 + 0) * HC + 32 * j + li] = cs; st[(wave * 2 + 1) * HC + 32 * j + li] = cq; }
       }
+      __syncthreads();
+      if (t < 2 * HC) {                                          // one entry per 128-row tile: waves added in order
+        const int q = t / HC, col = t - q * HC;
+        const float v = ((st[(0 * 2 + q) * HC + col] + st[(1 * 2 + q) * HC + col]) + st[(2 * 2 + q) * HC + col]) + st[(3 * 2 + q) * HC + col];
+        a.cstat[((long)blockIdx.x * 2 + q) * HID + c * HC + col] = v;
+      }
+      // (st is rewritten only after the next chunk's barriers)
     } else {
       // ---- BatchNorm (folded scale / shift) + ReLU on the fp32 accumulators, bf16 into this wave's rows of Hc ---------------
 #pragma unroll
@@ -270,10 +285,8 @@ __global__ __launch_bounds__(256) void enc_mlp_bf16_kernel(const EncMlpArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const long gr = r0 + row;
-        const float rs = (a.rscale && gr < a.rows) ? a.rscale[gr / a.rs_rows] : 1.f;
         const float xv = bf2f(d < CP ? R[row * CP + d] : A[row * SA + d]);
-        A[row * SA + d] = (__bf16)(xv + rs * acc2[n][r]);
+        A[row * SA + d] = (__bf16)(xv + rsl[row] * acc2[n][r]);
       }
     }
     for (int f = lane; f < 32 * UPR; f += 64) {
@@ -286,8 +299,8 @@ __global__ __launch_bounds__(256) void enc_mlp_bf16_kernel(const EncMlpArgs a) {
 
 template <int DIM, int HID, int CP>
 constexpr int enc_mlp_lds_bytes(int pass) {
-  return pass == 1 ? 2 * (128 * (DIM + 8) + 64 * (DIM + 8))
-                   : 2 * (128 * (DIM + 8) + 64 * (DIM + 8) + 128 * 72 + DIM * 72 + 128 * CP) + 8 * HID;
+  return pass == 1 ? 2 * (128 * (DIM + 8) + 64 * (DIM + 8)) + 4 * 2 * 64 * 4
+                   : 2 * (128 * (DIM + 8) + 64 * (DIM + 8) + 128 * 72 + DIM * 72 + 128 * CP) + 8 * HID + 4 * 128;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -317,10 +330,10 @@ __global__ __launch_bounds__(256) void enc_merge_bf16_kernel(const EncMergeArgs 
     const int f = t + 256 * i, row = f / (4 * UE), rem = f - row * 4 * UE, tap = rem / UE, u = rem - tap * UE;
     const long r2 = r0 + row;
     const bool ok = r2 < a.rows2;
-    const long rr = ok ? r2 : 0;
-    const long b = rr / P2;
-    const int q = (int)(rr - b * P2), oy = q / a.W2, ox = q - oy * a.W2;
-    const long pix = (b * a.Hp + 2 * oy + (tap >> 1)) * a.Wp + 2 * ox + (tap & 1);
+    const unsigned rr = ok ? (unsigned)r2 : 0u;                  // rows2 < 2^31 (host check): 32-bit divisions
+    const unsigned b = rr / (unsigned)P2;
+    const int q = (int)(rr - b * (unsigned)P2), oy = q / a.W2, ox = q - oy * a.W2;
+    const long pix = ((long)b * a.Hp + 2 * oy + (tap >> 1)) * a.Wp + 2 * ox + (tap & 1);
     va[i] = ld16_or_zero(a.x1, pix * E + u * 8, ok);
   }
   auto fetch_w = [&](int tap) {
@@ -405,19 +418,28 @@ __global__ __launch_bounds__(256) void bn_apply_bf16_kernel(__bf16* __restrict__
   }
 }
 
-// AdaptiveAvgPool2d(1) over a (B, P, C) bf16 tensor -> (B, C) fp32 (fp64 partial sums like gap_kernel)
+// AdaptiveAvgPool2d(1) over a (B, P, C) bf16 tensor -> (B, C) fp32: thread = (8 channels, one of 256 / (C/8) position
+// lanes), 16-byte loads, fp64 partial sums combined in lane order like gap_kernel.  C % 8 == 0, C / 8 <= 256.
 __global__ __launch_bounds__(256) void gap_bf16_kernel(const __bf16* __restrict__ x, float* __restrict__ out, int P, int C) {
-  __shared__ double part[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
-  const long b = blockIdx.y;
-  double s = 0;
-  if (c < C)
-    for (int p = r; p < P; p += 4) s += (double)(float)x[(b * P + p) * C + c];
-  part[r][threadIdx.x & 63] = s;
+  __shared__ double part[256][8];
+  const int C8 = C >> 3, lanes = 256 / C8, t = threadIdx.x;
+  const int c8 = t % C8, pl = t / C8;
+  const long b = blockIdx.x;
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (pl < lanes)
+    for (int p = pl; p < P; p += lanes) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (b * P + p) * C + c8 * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += (double)(float)v[k];
+    }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) part[t][k] = s[k];
   __syncthreads();
-  if (r == 0 && c < C) {
-    const double tt = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
-    out[b * C + c] = (float)(tt / (double)P);
+  if (t < C) {
+    const int cc = t >> 3, k = t & 7;
+    double tt = 0;
+    for (int l = 0; l < lanes; ++l) tt += part[l * C8 + cc][k];
+    out[b * C + t] = (float)(tt / (double)P);
   }
 }
 
