@@ -63,6 +63,42 @@ def build(force=False, verbose=True):
     return OUT
 
 
+SAN_OUT = os.path.join(HERE, "lib", "libporl_hip_host_san.so")
+SAN_DRIVER_SRC = os.path.join(os.path.dirname(HERE), "tests", "helpers", "abi_reject.cpp")
+SAN_DRIVER = os.path.join(HERE, "lib", "abi_reject_san")
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+
+
+def build_sanitized(force=False, verbose=True):
+    """The same translation unit with AddressSanitizer + UBSan on the HOST half (planner, validation, layout code; the
+    device half is compiled as usual and never runs), plus the driver that walks the rejected-argument paths
+    (tests/helpers/abi_reject.cpp).  CPU-only check: GPU sanitizers are not available on this pool.  Returns the
+    driver's path; cached by source hash like the product library."""
+    import hashlib
+    h = hashlib.sha256((source_hash() + open(SAN_DRIVER_SRC).read()).encode()).hexdigest()
+    tag = SAN_OUT + ".srchash"
+    try:
+        if not force and os.path.exists(SAN_OUT) and os.path.exists(SAN_DRIVER) and open(tag).read().strip() == h:
+            return SAN_DRIVER
+    except OSError:
+        pass
+    os.makedirs(os.path.dirname(SAN_OUT), exist_ok=True)
+    clangxx = os.path.join(os.path.dirname(os.path.dirname(hipcc())), "lib", "llvm", "bin", "clang++")
+    cmds = [[hipcc(), "--offload-arch=gfx950", "-fno-gpu-sanitize", *SAN_FLAGS, "-O1", "-std=c++17", "-shared", "-fPIC",
+             "-o", SAN_OUT, SRC],
+            [clangxx if os.path.exists(clangxx) else "clang++", "-std=c++17", "-O1", "-g", *SAN_FLAGS, "-o", SAN_DRIVER,
+             SAN_DRIVER_SRC, SAN_OUT, "-Wl,-rpath," + os.path.dirname(SAN_OUT)]]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL if not verbose else None)
+    with open(tag, "w") as f:
+        f.write(h + "\n")
+    return SAN_DRIVER
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(OUT)
+    if "--sanitized" in sys.argv:
+        print(build_sanitized(force="--force" in sys.argv))

@@ -96,3 +96,19 @@ def test_product_never_imports_oracle():
                         mods = [node.module]
                     bad += [(f, m) for m in mods if m.split(".")[0] == "oracle"]
     assert not bad, bad
+
+
+def test_host_planner_under_sanitizers():
+    """the host half of csrc/porl_api.hip (validation, layout, planning) built with
+    -fsanitize=address,undefined and driven over the rejected-argument paths and the pure-host queries of every engine
+    (tests/helpers/abi_reject.cpp: no kernel launch, so no GPU is needed).  The driver returns 0 only when every bad call
+    came back as a clean error with a message; the sanitizers abort the process on any finding."""
+    import subprocess
+    from porl_amd.build import build_sanitized
+    driver = build_sanitized(verbose=False)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([driver], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "0 unexpected" in r.stdout and "checks" in r.stdout
+    n = int(r.stdout.split("abi_reject:")[1].split("checks")[0])
+    assert n >= 100

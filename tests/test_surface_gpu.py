@@ -47,7 +47,7 @@ def test_twinq_valuefunction_deterministic_policy_forward_and_gradients(B, S, A,
     _close(v, rv[:, 0], "v")
     rp, cp = O.mlp_forward(P, "net", s.numpy(), L, out_act="tanh")
     act = dp(s.to(DEV))
-    assert act.shape == (B, A) and float(act.abs().max()) <= 1.0
+    assert act.shape == (B, A) and float(act.detach().abs().max()) <= 1.0
     _close(act, rp, "deterministic policy")
     assert torch.equal(dp.act(s.to(DEV)), act) and not dp.act(s.to(DEV)).requires_grad
     # ---- gradients: d(sum of w * output)/d(parameters) and d/d(input) -------------------------------------------------
