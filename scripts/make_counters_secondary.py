@@ -1,5 +1,5 @@
 """Summaries of scripts/profile_counters_secondary.sh: per-launch HBM bytes (FETCH_SIZE / WRITE_SIZE passes, gfx950
-correction as in make_profiles_r02.py) and matrix-pipe activity (SQ pass) of the CQL step (config 3) and the SORL
+correction as in make_profiles.py) and matrix-pipe activity (SQ pass) of the CQL step (config 3) and the SORL
 encoder update (config 5), one JSON per workload."""
 import glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -38,7 +38,7 @@ for wl, cmd in (("cql", "bench.py --workload cql --steps 40 --warmup 5"),
             rec["hbm_bytes_per_launch"] = (2 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024
             rec["hbm_gbs"] = rec["hbm_bytes_per_launch"] / e["avg_ns"]
         out["kernels"][k] = rec
-    json.dump(out, open(os.path.join(OUT, "r02_counters_%s.json" % ("cql" if wl == "cql" else "sorl_enc")), "w"), indent=1)
+    json.dump(out, open(os.path.join(OUT, os.environ.get("PORL_ROUND", "r03") + "_counters_%s.json" % ("cql" if wl == "cql" else "sorl_enc")), "w"), indent=1)
     for k, r in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"])[:8]:
         print(f"{wl} {k[:60]:60s} {r['avg_us']:9.1f} us x{r['launches']:4d} mfma_util {r['mfma_util']:.3f} {r['tflops']:6.1f} TF  "
               f"hbm {r.get('hbm_bytes_per_launch', 0) / 1e6:9.2f} MB {r.get('hbm_gbs', 0):7.1f} GB/s")

@@ -1,10 +1,11 @@
-"""Turn the rocprofv3 outputs of scripts/profile_r02.sh (gpurun_out/r02/prof/*) into the committed summaries under
+"""Turn the rocprofv3 outputs of scripts/profile_round.sh (gpurun_out/<round>/prof/*, round = PORL_ROUND, default r03) into the committed summaries under
 profiles/: kernel-stats CSVs, the per-launch step table, HBM bytes per launch (FETCH_SIZE / WRITE_SIZE passes) and
 MFMA utilisation (SQ_* pass)."""
 import collections, csv, json, os, sqlite3, subprocess, sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(REPO, "gpurun_out", "r02", "prof")
+RD = os.environ.get("PORL_ROUND", "r03")
+P = os.path.join(REPO, "gpurun_out", RD, "prof")
 OUT = os.environ.get("PORL_PROFILES_OUT", os.path.join(REPO, "profiles"))    # on the GPU box: a directory under gpurun_out/
 os.makedirs(OUT, exist_ok=True)
 sys.path.insert(0, os.path.join(REPO, "scripts"))
@@ -24,15 +25,17 @@ def stats_csv(db, out):
             w.writerow([n, len(v), sum(v), round(sum(v) / len(v), 3), round(100.0 * sum(v) / total, 2), min(v), max(v)])
 
 
-for tag, name in (("por_serial", "r02_kernel_stats.csv"), ("por_pipelined", "r02_kernel_stats_pipelined.csv"),
-                  ("cql", "r02_kernel_stats_cql.csv"), ("enc_fp32", "r02_kernel_stats_sorl_enc.csv"),
-                  ("enc_bf16", "r02_kernel_stats_sorl_enc_bf16.csv")):
+for tag, name in (("por_serial", RD + "_kernel_stats.csv"), ("por_pipelined", RD + "_kernel_stats_pipelined.csv"),
+                  ("cql", RD + "_kernel_stats_cql.csv"), ("enc_fp32", RD + "_kernel_stats_sorl_enc.csv"),
+                  ("enc_bf16", RD + "_kernel_stats_sorl_enc_bf16.csv"), ("enc_bf16_84", RD + "_kernel_stats_sorl_enc_bf16_84x84.csv")):
+    if not os.path.exists(os.path.join(P, tag, "t_results.db")):
+        continue
     stats_csv(os.path.join(P, tag, "t_results.db"), os.path.join(OUT, name))
     js = os.path.join(P, tag + ".json")
     if os.path.exists(js):
         with open(js) as f, open(os.path.join(OUT, name.replace("kernel_stats", "bench_under_rocprof").replace(".csv", ".json")), "w") as g:
             g.write(f.read())
-with open(os.path.join(OUT, "r02_step_table.txt"), "w") as f:
+with open(os.path.join(OUT, RD + "_step_table.txt"), "w") as f:
     f.write("rocprofv3 --kernel-trace of `bench.py --steps 200 --warmup 20 --no-pipeline` (every update back to back on one "
             "stream, so each kernel has the chip to itself): average duration of the k-th launch of the update over the last "
             "150 updates.\n\n")
@@ -54,7 +57,7 @@ for k in list(hbm["kernels"]):                     # plain name -> the shape wit
     base = k.split("@")[0]
     if base not in hbm["kernels"] or hbm["kernels"][k]["hbm_bytes_per_launch"] > hbm["kernels"][base]["hbm_bytes_per_launch"]:
         hbm["kernels"][base] = dict(hbm["kernels"][k], shape=k)
-json.dump(hbm, open(os.path.join(OUT, "r02_hbm_traffic.json"), "w"), indent=1)
+json.dump(hbm, open(os.path.join(OUT, RD + "_hbm_traffic.json"), "w"), indent=1)
 
 m = table(os.path.join(P, "pmc_mfma", "t_results.db"), 2)
 SIMDS = 256 * 4
@@ -73,7 +76,7 @@ for k, e in m.items():
                         "mfma_util": e["SQ_VALU_MFMA_BUSY_CYCLES"] / SIMDS / busy if busy else 0.0,
                         "clock_ghz": busy / e["avg_ns"],
                         "tflops": e["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / e["avg_ns"] / 1e3}
-json.dump(mf, open(os.path.join(OUT, "r02_mfma_util.json"), "w"), indent=1)
+json.dump(mf, open(os.path.join(OUT, RD + "_mfma_util.json"), "w"), indent=1)
 for k, e in mf["kernels"].items():
     print(f"{k[:52]:52s} {e['avg_us']:8.1f} us  mfma_util {e['mfma_util']:.3f}  clock {e['clock_ghz']:.2f} GHz  {e['tflops']:.1f} TF")
-print(open(os.path.join(OUT, "r02_step_table.txt")).read())
+print(open(os.path.join(OUT, RD + "_step_table.txt")).read())

@@ -5,7 +5,8 @@
 # Separate rocprofv3 --pmc runs (never with a trace), program directly after `--`; summaries are written on the box.
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02/prof2
+RD=${PORL_ROUND:-r03}
+O=$R/gpurun_out/$RD/prof2
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 C="python3 $R/bench.py --workload cql --steps 40 --warmup 5 --no-cpu-baseline"
@@ -19,5 +20,5 @@ rocprofv3 --pmc WRITE_SIZE -d $O/enc_write -o t -- $S > /dev/null 2> $O/enc_writ
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES -d $O/enc_mfma -o t -- $S > /dev/null 2> $O/enc_mfma.err
 fi
 cd $R
-python3 scripts/make_counters_secondary.py $O $R/gpurun_out/r02/profiles_out
+python3 scripts/make_counters_secondary.py $O $R/gpurun_out/$RD/profiles_out
 rm -rf $O/*/
