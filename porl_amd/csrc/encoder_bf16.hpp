@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void enc_mlp_bf16_kernel(const EncMlpArgs a) {
   constexpr int ROWS = 128, HC = 64, SA = DIM + 8, SH = HC + 8, NC = HID / HC, NT2 = DIM / 32;
   constexpr int UPR = DIM / 8, CPU = CP / 8;                     // 16-byte units per row of A; of them from yc
   constexpr int NA = ROWS * UPR / 256, NW1 = HC * UPR / 256, NW2 = DIM * (HC / 8) / 256;
+  constexpr int NR = (ROWS * CPU + 255) / 256;
   static_assert(DIM % 32 == 0 && HID % HC == 0 && CP % 8 == 0 && ROWS * UPR % 256 == 0 && HC * UPR % 256 == 0 &&
                 DIM * (HC / 8) % 256 == 0, "tile shapes");
   extern __shared__ __attribute__((aligned(16))) unsigned char mlp_lds[];
@@ -150,16 +151,48 @@ __global__ __launch_bounds__(256) void enc_mlp_bf16_kernel(const EncMlpArgs a) {
   float* rsl = ab + 2 * HID;                                     // [ROWS]         (PASS 2: DropPath factor of each row)
   float* st = reinterpret_cast<float*>(W1c + HC * SA);           // [4][2][HC]     (PASS 1: the four waves' column sums)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, kh = lane >> 5;
-  const long r0 = (long)blockIdx.x * ROWS;
+  const long ntiles = (a.rows + ROWS - 1) / ROWS;
+  // PFA = persistent blocks (grid = resident blocks, each walking tiles blockIdx.x, + gridDim.x, ...) that request the
+  // next tile's operands under the current tile.  Built and measured in round 3, and OFF: the apply pass went from 224 to
+  // 336 VGPRs (96-wide: one block per CU instead of two) and to 512 + spills (192-wide); the statistics pass kept its
+  // registers but got SLOWER, 1.0 -> 1.64 ms per update at 360x256 — with one tile per block three 42 KB blocks share a
+  // CU and hide each other's round trips better than two persistent ones with a prefetch.  One tile per block it stays.
+  constexpr bool PFA = false;
 
-  // ---- requests: the A tile, the residual's first CP channels, weight chunk 0 ------------------------------------------
-  u32x4 va[NA], vw1[NW1], vw2[PASS == 2 ? NW2 : 1];
+  // PERSISTENT blocks: a block walks tiles blockIdx.x, + gridDim.x, ...; the next tile's operands (A, the residual's
+  // first CP channels) are requested into registers right after the current tile has been parked, and weight chunk 0 of
+  // the next tile under the current tile's last chunk, so a tile starts with its operands already on the chip.
+  u32x4 va[NA], vr[PASS == 2 ? NR : 1], vw1[NW1], vw2[PASS == 2 ? NW2 : 1];
+  auto fetch_a = [&](long r0) {
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int f = t + 256 * i, row = f / UPR, u = f - row * UPR;
-    const bool ok = r0 + row < a.rows;
-    va[i] = u < CPU ? ld16_or_zero(a.yc, (r0 + row) * CP + u * 8, ok) : ld16_or_zero(a.x, (r0 + row) * DIM + u * 8, ok);
-  }
+    for (int i = 0; i < NA; ++i) {
+      const int f = t + 256 * i, row = f / UPR, u = f - row * UPR;
+      const bool ok = r0 + row < a.rows;
+      va[i] = u < CPU ? ld16_or_zero(a.yc, (r0 + row) * CP + u * 8, ok) : ld16_or_zero(a.x, (r0 + row) * DIM + u * 8, ok);
+    }
+    if constexpr (PASS == 2) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int f = t + 256 * i, row = f / CPU, u = f - row * CPU;
+        const bool ok = f < ROWS * CPU && r0 + row < a.rows;
+        vr[i] = ld16_or_zero(a.x, (r0 + row) * DIM + u * 8, ok);
+      }
+    }
+  };
+  auto park_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int f = t + 256 * i, row = f / UPR, u = f - row * UPR;
+      *reinterpret_cast<u32x4*>(A + row * SA + u * 8) = va[i];
+    }
+    if constexpr (PASS == 2) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int f = t + 256 * i, row = f / CPU, u = f - row * CPU;
+        if (f < ROWS * CPU) *reinterpret_cast<u32x4*>(R + row * CP + u * 8) = vr[i];
+      }
+    }
+  };
   auto fetch_w = [&](int c) {
 #pragma unroll
     for (int i = 0; i < NW1; ++i) {
@@ -188,112 +221,117 @@ __global__ __launch_bounds__(256) void enc_mlp_bf16_kernel(const EncMlpArgs a) {
       }
     }
   };
+  long tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  fetch_a(tile * ROWS);
   fetch_w(0);
   if constexpr (PASS == 2) {
-    for (int i = t; i < ROWS * CPU; i += 256) {
-      const int row = i / CPU, u = i - row * CPU;
-      *reinterpret_cast<u32x4*>(R + row * CP + u * 8) = ld16_or_zero(a.x, (r0 + row) * DIM + u * 8, r0 + row < a.rows);
-    }
     for (int i = t; i < HID; i += 256) { ab[i] = a.alpha[i]; ab[HID + i] = a.beta[i]; }
-    // one (64-bit) division per row here instead of one per accumulator element in the epilogue
-    if (t < ROWS) rsl[t] = (a.rscale && r0 + t < a.rows) ? a.rscale[(r0 + t) / a.rs_rows] : 1.f;
-  }
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int f = t + 256 * i, row = f / UPR, u = f - row * UPR;
-    *reinterpret_cast<u32x4*>(A + row * SA + u * 8) = va[i];
-  }
-  park_w();
-  __syncthreads();
-
-  f32x16 acc2[PASS == 2 ? NT2 : 1];
-  if constexpr (PASS == 2) {
-#pragma unroll
-    for (int n = 0; n < NT2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[n][r] = 0.f;
   }
   const __bf16* arow = A + (32 * wave + li) * SA + kh * 8;
-  for (int c = 0; c < NC; ++c) {
-    if (c + 1 < NC) fetch_w(c + 1);                              // in flight under this chunk's matrix work
-    // ---- h chunk = A W1c^T: 32 rows x 64 hidden columns per wave ---------------------------------------------------
-    f32x16 acc1[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < DIM / 16; ++ks) {
-      const bf16x8 fa = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(W1c + (32 * j + li) * SA + ks * 16 + kh * 8);
-        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc1[j], 0, 0, 0);
-      }
+  for (; tile < ntiles; tile += PFA ? (long)gridDim.x : ntiles) {
+    const long r0 = tile * ROWS;
+    const bool has_next = PFA && tile + gridDim.x < ntiles;      // block-uniform; PASS 2: one tile per block
+    park_a();
+    park_w();
+    if constexpr (PASS == 2) {
+      // one (64-bit) division per row here instead of one per accumulator element in the epilogue
+      if (t < ROWS) rsl[t] = (a.rscale && r0 + t < a.rows) ? a.rscale[(r0 + t) / a.rs_rows] : 1.f;
     }
-    if constexpr (PASS == 1) {
-      // rows past the end of the tensor were loaded as zeros and h has no bias: they add nothing to either sum
+    __syncthreads();
+    if constexpr (PFA) { if (has_next) fetch_a((tile + gridDim.x) * ROWS); }      // in flight for the whole tile
+
+    f32x16 acc2[PASS == 2 ? NT2 : 1];
+    if constexpr (PASS == 2) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float cs = 0.f, cq = 0.f;
+      for (int n = 0; n < NT2; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { cs += acc1[j][r]; cq = fmaf(acc1[j][r], acc1[j][r], cq); }
-        cs += __shfl_xor(cs, 32);
-        cq += __shfl_xor(cq, 32);
-        if (kh == 0) { st[(wave * 2 + 0) * HC + 32 * j + li] = cs; st[(wave * 2 + 1) * HC + 32 * j + li] = cq; }
-      }
-      __syncthreads();
-      if (t < 2 * HC) {                                          // one entry per 128-row tile: waves added in order
-        const int q = t / HC, col = t - q * HC;
-        const float v = ((st[(0 * 2 + q) * HC + col] + st[(1 * 2 + q) * HC + col]) + st[(2 * 2 + q) * HC + col]) + st[(3 * 2 + q) * HC + col];
-        a.cstat[((long)blockIdx.x * 2 + q) * HID + c * HC + col] = v;
-      }
-      // (st is rewritten only after the next chunk's barriers)
-    } else {
-      // ---- BatchNorm (folded scale / shift) + ReLU on the fp32 accumulators, bf16 into this wave's rows of Hc ---------------
+        for (int r = 0; r < 16; ++r) acc2[n][r] = 0.f;
+    }
+    for (int c = 0; c < NC; ++c) {
+      if (c + 1 < NC) fetch_w(c + 1);                            // in flight under this chunk's matrix work
+      else if (has_next) fetch_w(0);                             // the next tile starts with its first chunk on the chip
+      // ---- h chunk = A W1c^T: 32 rows x 64 hidden columns per wave ---------------------------------------------------
+      f32x16 acc1[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = c * HC + 32 * j + li;
-        const float al = ab[col], be = ab[HID + col];
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          Hc[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh) * SH + 32 * j + li] = (__bf16)fmaxf(fmaf(acc1[j][r], al, be), 0.f);
-      }
-      // (the wave reads back only rows it wrote itself; LDS operations of one wave complete in order)
-      const __bf16* hrow = Hc + (32 * wave + li) * SH + kh * 8;
+        for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < HC / 16; ++ks) {
-        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(hrow + ks * 16);
+      for (int ks = 0; ks < DIM / 16; ++ks) {
+        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
 #pragma unroll
-        for (int n = 0; n < NT2; ++n) {
-          const bf16x8 fb = *reinterpret_cast<const bf16x8*>(W2c + (32 * n + li) * SH + ks * 16 + kh * 8);
-          acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc2[n], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          const bf16x8 fb = *reinterpret_cast<const bf16x8*>(W1c + (32 * j + li) * SA + ks * 16 + kh * 8);
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc1[j], 0, 0, 0);
         }
       }
-    }
-    if (c + 1 < NC) {
-      __syncthreads();                                           // every wave is done with this chunk's weights
-      park_w();
-      __syncthreads();
-    }
-  }
-  if constexpr (PASS == 2) {
-    // ---- x + rscale * y2, bf16, through this wave's rows of the A tile, out as 16-byte pieces ----------------------------
+      if constexpr (PASS == 1) {
+        // rows past the end of the tensor were loaded as zeros and h has no bias: they add nothing to either sum
 #pragma unroll
-    for (int n = 0; n < NT2; ++n) {
-      const int d = 32 * n + li;
+        for (int j = 0; j < 2; ++j) {
+          float cs = 0.f, cq = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const float xv = bf2f(d < CP ? R[row * CP + d] : A[row * SA + d]);
-        A[row * SA + d] = (__bf16)(xv + rsl[row] * acc2[n][r]);
+          for (int r = 0; r < 16; ++r) { cs += acc1[j][r]; cq = fmaf(acc1[j][r], acc1[j][r], cq); }
+          cs += __shfl_xor(cs, 32);
+          cq += __shfl_xor(cq, 32);
+          if (kh == 0) { st[(wave * 2 + 0) * HC + 32 * j + li] = cs; st[(wave * 2 + 1) * HC + 32 * j + li] = cq; }
+        }
+        __syncthreads();
+        if (t < 2 * HC) {                                        // one entry per 128-row tile: waves added in order
+          const int q = t / HC, col = t - q * HC;
+          const float v = ((st[(0 * 2 + q) * HC + col] + st[(1 * 2 + q) * HC + col]) + st[(2 * 2 + q) * HC + col]) + st[(3 * 2 + q) * HC + col];
+          a.cstat[(tile * 2 + q) * HID + c * HC + col] = v;
+        }
+        if (PFA && c + 1 == NC) __syncthreads();                 // (st is rewritten only after the next chunk's barriers; a
+                                                                 //  persistent block's next tile starts with none)
+      } else {
+        // ---- BatchNorm (folded scale / shift) + ReLU on the fp32 accumulators, bf16 into this wave's rows of Hc -------------
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = c * HC + 32 * j + li;
+          const float al = ab[col], be = ab[HID + col];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            Hc[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh) * SH + 32 * j + li] = (__bf16)fmaxf(fmaf(acc1[j][r], al, be), 0.f);
+        }
+        // (the wave reads back only rows it wrote itself; LDS operations of one wave complete in order)
+        const __bf16* hrow = Hc + (32 * wave + li) * SH + kh * 8;
+#pragma unroll
+        for (int ks = 0; ks < HC / 16; ++ks) {
+          const bf16x8 fa = *reinterpret_cast<const bf16x8*>(hrow + ks * 16);
+#pragma unroll
+          for (int n = 0; n < NT2; ++n) {
+            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(W2c + (32 * n + li) * SH + ks * 16 + kh * 8);
+            acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc2[n], 0, 0, 0);
+          }
+        }
+      }
+      if (c + 1 < NC) {
+        __syncthreads();                                         // every wave is done with this chunk's weights
+        park_w();
+        __syncthreads();
       }
     }
-    for (int f = lane; f < 32 * UPR; f += 64) {
-      const int row = 32 * wave + f / UPR, u = f % UPR;
-      if (r0 + row < a.rows)
-        *reinterpret_cast<u32x4*>(a.out + (r0 + row) * DIM + u * 8) = *reinterpret_cast<const u32x4*>(A + row * SA + u * 8);
+    if constexpr (PASS == 2) {
+      // ---- x + rscale * y2, bf16, through this wave's rows of the A tile, out as 16-byte pieces ----------------------------
+#pragma unroll
+      for (int n = 0; n < NT2; ++n) {
+        const int d = 32 * n + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          const float xv = bf2f(d < CP ? R[row * CP + d] : A[row * SA + d]);
+          A[row * SA + d] = (__bf16)(xv + rsl[row] * acc2[n][r]);
+        }
+      }
+      for (int f = lane; f < 32 * UPR; f += 64) {
+        const int row = 32 * wave + f / UPR, u = f % UPR;
+        if (r0 + row < a.rows)
+          *reinterpret_cast<u32x4*>(a.out + (r0 + row) * DIM + u * 8) = *reinterpret_cast<const u32x4*>(A + row * SA + u * 8);
+      }
     }
+    if (has_next) __syncthreads();                               // every wave is done with this tile's images
   }
 }
 
