@@ -326,8 +326,10 @@ def _committed_traffic(fname, kernel):
     try:
         tj = json.load(open(os.path.join(REPO, "profiles", fname)))
         k = tj["kernels"]
+        import re
+        norm = lambda n: re.sub(r"\d", "", n.split("@")[0].split("<")[0].split(":")[-1])     # qnet_fused2_kernel<32>@128 -> qnet_fused_kernel
         for name, v in k.items():
-            if name == kernel or name.split("<")[0] == kernel.split("<")[0].split(":")[-1]:
+            if name == kernel or norm(name) == norm(kernel):
                 return v.get("hbm_bytes_per_launch")
     except Exception:
         pass
