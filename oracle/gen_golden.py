@@ -17,11 +17,11 @@ What is pinned:
   fasternet_*: FasterNet(3, 256).forward_cls (/root/reference/agent/fasternet.py:428-438) in eval mode and in
             train mode (batch-stat BatchNorm, running-stat update, DropPath masks replayed from the seed)
   sorl_enc_*: SORL.update with the FasterNet backbone (/root/reference/agent/sorl.py:78-128)
-  per_*   : PrioritizedReplayBuffer.add/sample/update_priorities under random.seed; per_trainer_*: PERTrainer.learn; dqn_* / ddqn_*: DQNTrainer.learn / DDQNTrainer.learn
+  per_*   : PrioritizedReplayBuffer.add/sample/update_priorities under random.seed; per_trainer_*: PERTrainer.learn; dqn_* / ddqn_*: DQNTrainer.learn / DDQNTrainer.learn; dddqn_*: DDDQNTrainer.learn on DuelingQNetwork
             (/root/reference/src/porl/train/dqn_per_trainer.py:67-123)
             (/root/reference/src/porl/buffer/prioritized_replay_buffer.py:36-108, sum_tree.py:4-77)
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py </dev/null
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [dddqn] </dev/null
 """
 from __future__ import annotations
 
@@ -548,6 +548,44 @@ def gen_dqn(name, double, S=10, A=6, B=64, K=5, N=500, seed_model=4, seed_data=2
     print(f"{name}: loss={losses}")
 
 
+def gen_dddqn(name, S=10, A=6, B=64, K=5, N=500, seed_model=8, seed_data=37, seed_np=5, gamma=0.99):
+    """DDDQNTrainer.learn (src/porl/train/dddqn_trainer.py:59-103: Double-DQN target) on DuelingQNetwork pairs
+    (src/porl/net/q_network.py:33-68: value + advantage streams on 64 features, q = v + a - mean(a)), as an unbound method
+    on a hand-built object (the constructor needs gymnasium); numpy's index stream pinned by np.random.seed."""
+    _stub_cql_imports()
+    from porl.train.dddqn_trainer import DDDQNTrainer
+    from porl.net.q_network import DuelingQNetwork
+    from porl.buffer.replaybuffer import ReplayBuffer
+    dev = torch.device("cpu")
+    torch.manual_seed(seed_model)
+    t = object.__new__(DDDQNTrainer)
+    t.q_network = DuelingQNetwork(S, A).to(dev)
+    t.target_network = DuelingQNetwork(S, A).to(dev)
+    t.target_network.load_state_dict(t.q_network.state_dict())
+    with torch.no_grad():
+        for p in t.target_network.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    t.optimizer = torch.optim.Adam(t.q_network.parameters(), lr=0.0005)
+    t.replay_buffer = ReplayBuffer(N, (S,), dev)
+    t.batch_size, t.gamma, t.device = B, gamma, dev
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=seed_data)
+    for i in range(N):
+        t.replay_buffer.push(st[i], int(ac[i]), float(rw[i]), ns[i], bool(dn[i]))
+    out = {"meta": np.array([S, A, B, K, N, seed_model, seed_data, seed_np]), "gamma": np.float64(gamma)}
+    out.update(pack("init/", sd_np(t.q_network)))
+    out.update(pack("init_target/", sd_np(t.target_network)))
+    probe = torch.from_numpy(st[:4])
+    out["probe_x"] = st[:4]
+    out["probe_q0"] = t.q_network(probe).detach().numpy()
+    np.random.seed(seed_np)
+    losses = [DDDQNTrainer.learn(t) for _ in range(K)]
+    out["loss"] = np.array(losses, dtype=np.float64)
+    out.update(pack("final/", sd_np(t.q_network)))
+    out["probe_q"] = t.q_network(probe).detach().numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={losses}")
+
+
 def gen_bcq(name, S=10, A=6, B=64, K=5, KP=6, N=500, seed_model=5, seed_data=31, seed_np=11, gamma=0.99, threshold=0.17):
     """bcq_behavior_pretrain (src/porl/policy/bcq.py:23-47) for KP epochs, then bcq_learn (:50-86) for K steps, on a
     hand-built BCQTrainer (its constructor needs gymnasium); numpy's index stream pinned by np.random.seed.  The
@@ -729,6 +767,9 @@ def sub_dict(d, prefix):
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:                      # `gen_golden.py dddqn`: (re)generate one fixture family only
+        {"dddqn": lambda: gen_dddqn("dddqn_s10_a6")}[sys.argv[1]]()
+        return
     # POR — small, fully stored
     gen_por("por_s60_h64_b32", S=60, H=64, L=2, layer_norm=False, B=32, K=5, full=True)
     gen_por("por_s60_h64_b32_ln", S=60, H=64, L=2, layer_norm=True, B=32, K=5, full=True)
@@ -760,6 +801,7 @@ def main():
     gen_dqn("dqn_s10_a6", double=False)
     gen_dqn("ddqn_s10_a6", double=True)
     gen_bcq("bcq_s10_a6")
+    gen_dddqn("dddqn_s10_a6")
     gen_qr("qrdqn_s9_a5_n12")
     gen_c51("c51_s9_a5_n21")
     gen_iqn_loss("iqn_quantile_huber")

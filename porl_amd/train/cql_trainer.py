@@ -23,7 +23,7 @@ import torch.nn as nn
 from .. import _native as N
 from ..buffer.replay_buffer import ReplayBuffer
 from ..engine import _norm_device
-from ..net.q_network import QNetwork
+from ..net.q_network import DuelingQNetwork, QNetwork
 from ..parallel import GradExchange
 from ..utils.logger import Logger
 
@@ -103,9 +103,21 @@ class QnetEngine:
     def hyper(self, gamma, alpha, inv_batch, step, lr, betas=(0.9, 0.999), eps=1e-8):
         return N.QnetHyper(gamma, alpha, inv_batch, step, lr, betas[0], betas[1], eps)
 
+    post_step = None      # callable(hp) run after every optimizer step of this engine (dueling heads: _DuelingHeads)
+
+    def _stepped(self, hp):
+        if self.post_step is not None:
+            self.post_step(hp)
+
     def cql_backward(self, hp): N.check(self._lib.porl_qnet_cql_backward(self._h, C.byref(hp), N.current_stream_ptr(self.device)), "porl_qnet_cql_backward")
-    def apply(self, hp): N.check(self._lib.porl_qnet_apply(self._h, C.byref(hp), N.current_stream_ptr(self.device)), "porl_qnet_apply")
-    def learn(self, hp): N.check(self._lib.porl_qnet_learn(self._h, C.byref(hp), N.current_stream_ptr(self.device)), "porl_qnet_learn")
+
+    def apply(self, hp):
+        N.check(self._lib.porl_qnet_apply(self._h, C.byref(hp), N.current_stream_ptr(self.device)), "porl_qnet_apply")
+        self._stepped(hp)
+
+    def learn(self, hp):
+        N.check(self._lib.porl_qnet_learn(self._h, C.byref(hp), N.current_stream_ptr(self.device)), "porl_qnet_learn")
+        self._stepped(hp)
 
     def learn_indexed(self, hp, states, actions, rewards, next_states, dones, idx, variant=None):
         """learn() on rows `idx` (int64, device) of device-resident replay arrays: gathered inside the one-launch step
@@ -133,6 +145,7 @@ class QnetEngine:
                                                       N.ptr(rewards), N.ptr(next_states), self.cfg.state_dim, N.ptr(dones),
                                                       N.ptr(idx), B, C.byref(hp), C.byref(variant),
                                                       N.current_stream_ptr(self.device)), "porl_qnet_learn_variant")
+        self._stepped(hp)
         return B
 
     def learn_sampled(self, hp, states, actions, rewards, next_states, dones, n_rows, batch, seed, draw):
@@ -152,15 +165,20 @@ class QnetEngine:
                                                   N.ptr(next_states), self.cfg.state_dim, N.ptr(dones), int(n_rows),
                                                   int(seed), int(draw), int(batch), C.byref(hp),
                                                   N.current_stream_ptr(self.device)), "porl_qnet_learn_sampled")
+        self._stepped(hp)
         return batch
 
     @property
     def can_sample(self):
         return bool(self._lib.porl_qnet_can_sample(self._h))
 
+    post_sync = None      # callable() run after the target network was overwritten (dueling heads)
+
     def sync_target(self):
         self._ensure_bound()
         N.check(self._lib.porl_qnet_sync_target(self._h, N.current_stream_ptr(self.device)), "porl_qnet_sync_target")
+        if self.post_sync is not None:
+            self.post_sync()
 
     def forward(self, x, which=0):
         self._ensure_bound()
@@ -187,6 +205,76 @@ class QnetEngine:
                 self._h = None
         except Exception:
             pass
+
+
+class _DuelingHeads:
+    """True parameters of a DuelingQNetwork pair's heads (reference q_network.py:41-49) beside an engine whose output layer
+    is the COMPOSED layer  W_eff = M [w_v; W_a],  b_eff = M [b_v; b_a]  with the constant M = [1 | I - 11^T/A] (A, A+1).
+
+    Storage per network: one flat (A+1, F+1) fp32 tensor, row 0 = [w_v | b_v], rows 1.. = [W_a[j] | b_a[j]]; the module's
+    `value.0.*` / `advantage.0.*` parameters are (strided) views of it, Adam moments mirror it.  After every optimizer step
+    of the engine: gather the output layer's gradient (A, F+1) from the engine's gradient group, map it back with
+    M^T (one TN product on porl_gemm_f32), torch-exact Adam on the heads (porl_adam_ema, the trainer's step counter and
+    hyper-parameters), compose (one NN product) and write the composed layer into the engine's parameter image.  The
+    engine's own Adam also steps the composed layer — overwritten right away, its moments are never used.  All arithmetic
+    is HIP kernels; torch only copies between strided views."""
+
+    def __init__(self, trainer, q_network, target_network):
+        eng = trainer._engine
+        self.trainer, self.eng = trainer, eng
+        A, F = eng.cfg.n_actions, 64
+        self.A, self.F = A, F
+        dev = eng.device
+        n = ((A + 1) * (F + 1) + 3) // 4 * 4
+        z = lambda: torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat, self.flat_tgt, self.grad, self.m, self.v = z(), z(), z(), z(), z()
+        M = torch.zeros(A, A + 1, dtype=torch.float32)
+        M[:, 0] = 1.0
+        M[:, 1:] = torch.eye(A) - 1.0 / A
+        self.M = M.to(dev)
+        self.g_ext = torch.zeros(A, F + 1, dtype=torch.float32, device=dev)
+        self.w_ext = torch.zeros(A, F + 1, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for mod, flat in ((q_network, self.flat), (target_network, self.flat_tgt)):
+                hd = flat[:(A + 1) * (F + 1)].view(A + 1, F + 1)
+                for p, v in ((mod.value[0].weight, hd[0:1, :F]), (mod.value[0].bias, hd[0, F:F + 1]),
+                             (mod.advantage[0].weight, hd[1:, :F]), (mod.advantage[0].bias, hd[1:, F])):
+                    v.copy_(p)
+                    p.data = v
+        self.compose(0)
+        self.flat_tgt_sync = False
+
+    def _hd(self, flat):
+        return flat[:(self.A + 1) * (self.F + 1)].view(self.A + 1, self.F + 1)
+
+    def compose(self, which):
+        """Write the composed output layer of the online (0) / target (1) network into the engine's parameter image."""
+        from .. import engine as E
+        A, F, eng = self.A, self.F, self.eng
+        hd = self._hd(self.flat if which == 0 else self.flat_tgt)
+        E.gemm_f32(1, self.M, hd, A, F + 1, A + 1, A + 1, F + 1, self.w_ext, F + 1)          # (A, A+1) x (A+1, F+1)
+        views = eng.views(eng.params if which == 0 else eng.params_tgt)
+        with torch.no_grad():
+            views[-2].copy_(self.w_ext[:, :F])
+            views[-1].copy_(self.w_ext[:, F])
+
+    def after_step(self, hp):
+        from .. import engine as E
+        A, F, eng = self.A, self.F, self.eng
+        gv = eng.views(eng.grads)
+        with torch.no_grad():
+            self.g_ext[:, :F].copy_(gv[-2])
+            self.g_ext[:, F].copy_(gv[-1])
+        # d(heads) = M^T d(composed layer): "TN" product, contraction over the A composed rows
+        E.gemm_f32(2, self.M, self.g_ext, A + 1, F + 1, A, A + 1, F + 1, self._hd(self.grad), F + 1)
+        g = self.trainer.optimizer.param_groups[0]
+        E.adam_ema(self.flat, self.grad, self.m, self.v, None, hp.lr, hp.step, g["betas"][0], g["betas"][1], g["eps"], 0.0)
+        self.compose(0)
+
+    def after_sync(self):
+        with torch.no_grad():
+            self.flat_tgt.copy_(self.flat)
+        # (the engine copied the online image, composed layer included, into the target image)
 
 
 class _FlatAdam:
@@ -222,19 +310,32 @@ class CQLTrainer:
         # action_size) -> QNetwork, e.g. `lambda s, a: QNetwork(s, a, [256, 256])` for other hidden sizes
         self.q_network = network(state_size, action_size)
         self.target_network = network(state_size, action_size)
-        if not isinstance(self.q_network, QNetwork) or not isinstance(self.target_network, QNetwork):
-            raise NotImplementedError("only QNetwork (a plain Linear/ReLU chain) is on the accelerated path; "
-                                      "DuelingQNetwork (q_network.py:33-68) is not provided")
+        dueling = isinstance(self.q_network, DuelingQNetwork) and isinstance(self.target_network, DuelingQNetwork)
+        if not dueling and (not isinstance(self.q_network, QNetwork) or not isinstance(self.target_network, QNetwork)):
+            raise NotImplementedError("QNetwork (a plain Linear/ReLU chain) and DuelingQNetwork are on the accelerated path")
         hidden = self.q_network._spec[2]
         self._engine = QnetEngine(state_size, action_size, hidden, max(max_batch, batch_size), self.device)
         with torch.no_grad():
             for mod, flat, which in ((self.q_network, self._engine.params, 0),
                                      (self.target_network, self._engine.params_tgt, 1)):
-                for p, v in zip(mod.parameters(), self._engine.views(flat)):
+                # dueling: `model` holds the hidden layers only; the engine's output layer is the composed layer
+                owned = list(mod.model.parameters()) if dueling else list(mod.parameters())
+                for p, v in zip(owned, self._engine.views(flat)):
                     v.copy_(p)
                     p.data = v
                 mod._engine, mod._which = self._engine, which
-            self._engine.params_tgt.copy_(self._engine.params)       # target.load_state_dict(q.state_dict())
+            if not dueling:
+                self._engine.params_tgt.copy_(self._engine.params)   # target.load_state_dict(q.state_dict())
+        self._dueling = None
+        if dueling:
+            self._engine._ensure_bound()
+            self._dueling = _DuelingHeads(self, self.q_network, self.target_network)
+            # target.load_state_dict(q.state_dict()) (dqn_trainer.py:68): hidden layers, composed layer and heads
+            self._engine.params_tgt.copy_(self._engine.params)
+            self._dueling.after_sync()
+            self._engine.post_step, self._engine.post_sync = self._dueling.after_step, self._dueling.after_sync
+            for mod, which in ((self.q_network, 0), (self.target_network, 1)):
+                mod.register_load_state_dict_post_hook(lambda module, incompatible, w=which: self._dueling.compose(w))
         self.target_network.eval()
         self.optimizer = _FlatAdam(self._engine, list(self.q_network.parameters()), learning_rate)
         self.replay_buffer = replay_buffer if replay_buffer is not None else ReplayBuffer(100000, (state_size,), self.device)

@@ -369,3 +369,38 @@ def test_bcq_mask_with_no_allowed_action_falls_back_to_the_first_action():
     y = rw[idx] + 0.9 * tq[:, 0] * (1 - dn[idx])
     want = np.mean((q[np.arange(B), ac[idx]] - y) ** 2)
     np.testing.assert_allclose(loss, want, rtol=2e-5)
+
+
+@pytest.mark.parametrize("qnet_path", ["fused", "general"], indirect=True)
+def test_dueling_double_dqn_learn_matches_reference_golden(qnet_path):
+    """DDDQNTrainer.learn (dddqn_trainer.py:59-103) with DuelingQNetwork pairs (q_network.py:33-68): five steps under the
+    reference's numpy index stream from the reference's initial online / target parameters.  The heads ride on the engine
+    as a composed output layer; value.* / advantage.* / model.* must all follow the reference."""
+    from porl_amd.net.q_network import DuelingQNetwork
+    from porl_amd.train.dddqn_trainer import DDDQNTrainer
+    z, _ = load_golden("dddqn_s10_a6")
+    S, A, B, K, N, seed_model, seed_data, seed_np = (int(v) for v in z["meta"])
+    torch.manual_seed(seed_model)
+    t = DDDQNTrainer(S, A, float(z["gamma"]), device=DEV, batch_size=B)
+    assert isinstance(t.q_network, DuelingQNetwork) and list(t.q_network.state_dict().keys()) == list(sub(z, "init/").keys())
+    for k, v in sub(z, "init/").items():                          # same seed: the reference's own initialisation
+        np.testing.assert_array_equal(t.q_network.state_dict()[k].cpu().numpy(), v, err_msg=k)
+    t.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in sub(z, "init_target/").items()})
+    x = torch.from_numpy(z["probe_x"]).to(DEV)
+    np.testing.assert_allclose(t.q_network(x).cpu().numpy(), z["probe_q0"], atol=2e-6)
+    st, ac, rw, ns, dn = make_discrete_transitions(N, S, A, seed=seed_data)
+    t.replay_buffer = type(t.replay_buffer)(N, (S,), DEV)
+    for i in range(N):
+        t.replay_buffer.push(st[i], int(ac[i]), float(rw[i]), ns[i], bool(dn[i]))
+    np.random.seed(seed_np)
+    for k in range(K):
+        np.testing.assert_allclose(t.learn(), z["loss"][k], rtol=2e-5)
+    got = _np_sd(t.q_network)
+    for k, v in sub(z, "final/").items():
+        np.testing.assert_allclose(got[k], v, atol=1e-5, err_msg=k)
+    np.testing.assert_allclose(t.q_network(x).cpu().numpy(), z["probe_q"], atol=5e-6)
+    # hard target sync copies heads and composed layer
+    t.sync_target()
+    np.testing.assert_array_equal(t.target_network(x).cpu().numpy(), t.q_network(x).cpu().numpy())
+    for k, v in t.q_network.state_dict().items():
+        assert torch.equal(v, t.target_network.state_dict()[k]), k
