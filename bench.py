@@ -582,6 +582,14 @@ def por_rank(a, force_dp):
 
     def timed_run(mode, steps, warmup, keep=False):
         """W warm-up updates, then exactly K timed updates bracketed by barrier + device synchronisation; MAX over ranks."""
+        prio = os.environ.get("PORL_BENCH_MAIN_PRIORITY")            # A/B: the value phase's stream at another priority
+        if prio is not None and not getattr(timed_run, "_in_prio", False):
+            timed_run._in_prio = True
+            try:
+                with torch.cuda.stream(torch.cuda.Stream(device=dev, priority=int(prio))):
+                    return timed_run(mode, steps, warmup, keep)
+            finally:
+                timed_run._in_prio = False
         agent = make_agent(mode)
         replay.draws = 0
         losses = torch.zeros(steps + warmup, 8, device=dev)       # device-side loss history, one row per update

@@ -287,8 +287,21 @@ class _FlatAdam:
     def zero_grad(self, set_to_none=True):
         pass
 
-    def state_dict(self):
+    _dueling = None       # _DuelingHeads of a DuelingQNetwork trainer: the heads' moments live beside the engine's
+
+    def _moments(self):
         ms, vs = self._eng.views(self._eng.adam_m), self._eng.views(self._eng.adam_v)
+        if self._dueling is not None:
+            # q_network.parameters() order: value.w, value.b, advantage.w, advantage.b, then the hidden layers (the engine's
+            # last two tensors are the composed output layer, which is not a parameter)
+            d = self._dueling
+            hm, hv = d._hd(d.m), d._hd(d.v)
+            pick = lambda h: [h[0:1, :d.F], h[0, d.F:d.F + 1], h[1:, :d.F], h[1:, d.F]]
+            return pick(hm) + ms[:-2], pick(hv) + vs[:-2]
+        return ms, vs
+
+    def state_dict(self):
+        ms, vs = self._moments()
         state = {i: dict(step=torch.tensor(float(self.step_count)), exp_avg=m.clone(), exp_avg_sq=v.clone())
                  for i, (m, v) in enumerate(zip(ms, vs))} if self.step_count else {}
         g = {k: v for k, v in self.param_groups[0].items() if k != "params"}
@@ -338,6 +351,7 @@ class CQLTrainer:
                 mod.register_load_state_dict_post_hook(lambda module, incompatible, w=which: self._dueling.compose(w))
         self.target_network.eval()
         self.optimizer = _FlatAdam(self._engine, list(self.q_network.parameters()), learning_rate)
+        self.optimizer._dueling = self._dueling
         self.replay_buffer = replay_buffer if replay_buffer is not None else ReplayBuffer(100000, (state_size,), self.device)
         self.batch_size = batch_size
         self.logger = Logger(log_dir=log_dir)

@@ -399,6 +399,11 @@ def test_dueling_double_dqn_learn_matches_reference_golden(qnet_path):
     for k, v in sub(z, "final/").items():
         np.testing.assert_allclose(got[k], v, atol=1e-5, err_msg=k)
     np.testing.assert_allclose(t.q_network(x).cpu().numpy(), z["probe_q"], atol=5e-6)
+    # optimizer state in torch.optim.Adam's format, one entry per q_network parameter in its order
+    osd = t.optimizer.state_dict()
+    assert len(osd["state"]) == len(list(t.q_network.parameters())) == 10
+    for i, p_ in enumerate(t.q_network.parameters()):
+        assert tuple(osd["state"][i]["exp_avg"].shape) == tuple(p_.shape) and float(osd["state"][i]["step"]) == K
     # hard target sync copies heads and composed layer
     t.sync_target()
     np.testing.assert_array_equal(t.target_network(x).cpu().numpy(), t.q_network(x).cpu().numpy())
