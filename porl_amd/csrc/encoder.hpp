@@ -437,6 +437,104 @@ __global__ __launch_bounds__(64 * (OCB / 8)) void pconv3x3_kernel(const float* _
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Partial_conv3 on the fp32 MATRIX pipe (round 3): implicit GEMM, out (POS = 128 consecutive positions of one sample) x
+// (32 output channels per pass), K = 9 taps x CP input channels, v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains; the
+// summation order is (tap, ci) instead of the direct kernel's (ky, ci, kx): results agree to rounding).  The direct
+// kernel above runs 184 GFLOP per update on the vector ALU at 48 TFLOP/s (3.7 ms); the same work is ~25 % of one
+// matrix-pipe millisecond.  The touched input rows + halo (zeros outside the image) sit in LDS as [row][x][ci]
+// (ci-contiguous: a lane reads 4 consecutive ci with one 16-byte load, lane half kh takes ci = 8 g + 4 kh + j), the
+// weight of the current 32-channel pass as [tap][oc][ci] from the zero-padded image pack_pconv_mfma_kernel made.  Any
+// geometry.  Also copies the untouched channels CP..C-1 of its positions.
+//   x (B, H, W, C) -> y[:, :CP] = conv3x3(x[:, :CP]), y[:, CP:] = x[:, CP:]
+// ---------------------------------------------------------------------------------------------------
+struct PconvMfmaArgs {
+  const float* x; float* y; const float* w;     // w: [pass][tap][32][CP + 4]
+  int C, Hh, Ww, tiles_per_sample, tiles_total, tiles_per_block;
+};
+
+__global__ void pack_pconv_mfma_kernel(const float* __restrict__ src, float* __restrict__ dst, int CP, int npass) {
+  const int XS = CP + 4, n = npass * 9 * 32 * XS;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int ci = i % XS, oc = (i / XS) % 32, tap = (i / (XS * 32)) % 9, ps = i / (XS * 32 * 9);
+    const int o = ps * 32 + oc;
+    dst[i] = (o < CP && ci < CP) ? src[((long)o * CP + ci) * 9 + tap] : 0.f;
+  }
+}
+
+template <int CP>
+__global__ __launch_bounds__(256) void pconv_f32_mfma_kernel(const PconvMfmaArgs a) {
+  constexpr int XS = CP + 4, POS = 128, NPASS = (CP + 31) / 32, U = CP / 4;
+  static_assert(CP % 8 == 0, "the k loop walks groups of 8 input channels");
+  extern __shared__ __attribute__((aligned(16))) float pm_lds[];
+  float* Wl = pm_lds;                               // [9][32][XS]
+  float* X = Wl + 9 * 32 * XS;                      // [nr][Ww + 2][XS]
+  typedef float pm_f32x16 __attribute__((ext_vector_type(16)));
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, kh = lane >> 5;
+  const int P = a.Hh * a.Ww, WW2 = a.Ww + 2;
+  for (int k = 0; k < a.tiles_per_block; ++k) {
+    const int gt = blockIdx.x * a.tiles_per_block + k;
+    if (gt >= a.tiles_total) break;                                // block-uniform
+    const int b = gt / a.tiles_per_sample, tile = gt - b * a.tiles_per_sample;
+    const int p0 = tile * POS, p1 = min(P, p0 + POS) - 1;
+    const int y_lo = p0 / a.Ww - 1, nr = p1 / a.Ww + 1 - y_lo + 1;
+    const float* xs = a.x + (long)b * P * a.C;
+    float* ys = a.y + (long)b * P * a.C;
+    if (k) __syncthreads();                                        // the previous tile's fragments have been read
+    for (int i = t; i < nr * WW2 * U; i += 256) {
+      const int pix = i / U, u = i - pix * U, ry = pix / WW2, rx = pix - ry * WW2;
+      const int yy = y_lo + ry, xx = rx - 1;
+      const bool ok = yy >= 0 && yy < a.Hh && xx >= 0 && xx < a.Ww;
+      const float4 v = *reinterpret_cast<const float4*>(xs + (ok ? ((long)yy * a.Ww + xx) * a.C + u * 4 : 0));
+      *reinterpret_cast<float4*>(X + pix * XS + u * 4) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int p = p0 + 32 * wave + li;
+    const int pc = p < P ? p : p0;                                 // lanes past the sample compute a valid pixel, unused
+    const int yy = pc / a.Ww, xx = pc - yy * a.Ww;
+    const float* xa = X + ((yy - y_lo) * WW2 + xx + 1) * XS + kh * 4;
+#pragma unroll 1
+    for (int ps = 0; ps < NPASS; ++ps) {
+      if (ps || k == 0 || NPASS > 1) {
+        if (ps) __syncthreads();                                   // every wave is done with the previous pass's weights
+        for (int i = t; i < 9 * 32 * XS / 4; i += 256)
+          reinterpret_cast<float4*>(Wl)[i] = reinterpret_cast<const float4*>(a.w + (long)ps * 9 * 32 * XS)[i];
+      }
+      __syncthreads();
+      pm_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* wb = Wl + li * XS + kh * 4;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int off = ((tap / 3 - 1) * WW2 + (tap % 3 - 1)) * XS;
+#pragma unroll
+        for (int g = 0; g < CP / 8; ++g) {
+          const float4 fa = *reinterpret_cast<const float4*>(xa + off + g * 8);
+          const float4 fb = *reinterpret_cast<const float4*>(wb + tap * 32 * XS + g * 8);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+        }
+      }
+      const int oc = ps * 32 + li;
+      if (oc < CP) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int pos = p0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (pos < P) ys[(long)pos * a.C + oc] = acc[r];
+        }
+      }
+    }
+    // the untouched channels of this tile's positions
+    const int rest4 = (a.C - CP) / 4, npos = p1 - p0 + 1;
+    for (int i = t; i < npos * rest4; i += 256) {
+      const int pos = p0 + i / rest4, c = CP + 4 * (i % rest4);
+      *reinterpret_cast<float4*>(ys + (long)pos * a.C + c) = *reinterpret_cast<const float4*>(xs + (long)pos * a.C + c);
+    }
+  }
+}
+
 // conv weight (Cp, Cp, 3, 3) -> [ky][ci][kx][oc], the order pconv3x3_kernel walks
 __global__ void pack_pconv_kernel(const float* __restrict__ src, float* __restrict__ dst, int CP) {
   const int n = CP * CP * 9;

@@ -134,6 +134,7 @@ inline int skinny_mask() { return g_short_blocks ? g_skinny_pipelined : g_skinny
 int g_dw0_slabs = 16;        // porl_tune_set("dw0_slabs", n <= SK_MAX): slabs of the skinny dW0 kernel (A/B: fewer slabs = fewer partial bytes, fewer blocks)
 int g_iql_fold = 1;          // porl_tune_set("iql_fold", 0): porl_iql_step keeps the slab combines as launches of their own (A/B)
 int g_enc_bf16_operands_only = 0;   // porl_tune_set("enc_bf16_operands_only", 1): compute_dtype="bf16" runs round 2's bf16-OPERAND mode (fp32 tensors in memory) instead of encoder_bf16.hpp (A/B)
+int g_enc_pconv_mfma = 0;    // porl_tune_set("enc_pconv_mfma", 1): the fp32 partial 3x3 conv as an implicit GEMM on the matrix pipe (round 3) instead of the direct vector-ALU kernel.  Measured SLOWER (5.8 vs 3.7 ms per update at 360x256 B=512): the step moves ~2.5 GB per stage-1 call (input tile, result, the copy of the untouched channels) and is bound by that, not by the 184 GFLOP; the MFMA form parks more LDS per block (77 / 117 KB) and hides less latency.  Kept as a cross-check (tests/test_fasternet_gpu.py)
 int g_enc_bn_sweep = 0;      // porl_tune_set("enc_bn_sweep", 1): BatchNorm + ReLU of the MLP blocks as a separate sweep (cross-check)
 int g_enc_dense_patch = 0;   // porl_tune_set("enc_dense_patch", 1): rasterise + dense patch embedding (cross-check)
 int g_qnet_fused = 1;     // porl_tune_set("qnet_fused", 0) forces the multi-launch CQL path (A/B measurements)
@@ -1484,6 +1485,7 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "enc_dense_patch")) { g_enc_dense_patch = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_s2d")) { g_enc_s2d = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_bn_sweep")) { g_enc_bn_sweep = value != 0; return PORL_OK; }
+  if (!strcmp(key, "enc_pconv_mfma")) { g_enc_pconv_mfma = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_bf16_operands_only")) { g_enc_bf16_operands_only = value != 0; return PORL_OK; }
   if (!strcmp(key, "iql_fold")) { g_iql_fold = value != 0; return PORL_OK; }
   if (!strcmp(key, "skinny")) { g_skinny = value == 1 ? 7 : value; return PORL_OK; }

@@ -384,3 +384,38 @@ def test_bf16_modes_stay_close_to_the_fp32_path(n_ang, n_dist, mode):
         elif "running_mean" in k:                        # channel means sit near zero: on the scale of the channel's deviation
             sd = np.sqrt(outs["fp32"][2][k.replace("running_mean", "running_var")].max() / 0.1)
             assert np.abs(outs[mode][2][k] - v).max() < 2e-2 * sd, k
+
+
+@pytest.mark.parametrize("n_ang,n_dist,B", [(360, 256, 7), (84, 84, 5), (40, 64, 3)])
+def test_partial_conv_on_the_matrix_pipe_agrees_with_the_direct_kernel(n_ang, n_dist, B):
+    """Partial_conv3 (fasternet.py:110-138) as an implicit GEMM on the fp32 matrix pipe (round 3; measured slower than the
+    direct kernel and therefore opt-in: porl_tune_set("enc_pconv_mfma", 1)) against the direct vector-ALU kernel /
+    patch-matrix path (the default): the same exact-fp32
+    products summed in another order — features agree to 2e-6 of their largest magnitude, in train mode (statistics
+    included) and in eval mode, for the reference's geometry and for odd row widths (21- and 10-wide rows: tiles that span
+    several image rows and end inside one)."""
+    from porl_amd import engine as E
+    from porl_amd.agent.fasternet import FasterNet
+    rng = np.random.default_rng(n_ang)
+    st = np.empty((B, n_ang + 2), dtype=np.float32)
+    st[:, :n_ang] = rng.uniform(0.2, 3.9, size=(B, n_ang))
+    st[:, n_ang:] = rng.uniform(-3, 3, size=(B, 2))
+    outs = []
+    for mfma in (1, 0):
+        try:
+            E.tune_set("enc_pconv_mfma", mfma)
+            torch.manual_seed(9)
+            m = FasterNet(3, 256, max_batch=8, angle_bins=n_ang, dist_bins=n_dist).to(DEV)
+            m.train()
+            scale = torch.ones(3, B)
+            scale[0, 1] = 0.0
+            a = m(torch.from_numpy(st.copy()).to(DEV), drop_scale=scale).cpu().numpy()
+            m.eval()
+            b = m(torch.from_numpy(st.copy()).to(DEV)).cpu().numpy()
+            outs.append((a, b, {k: v.cpu().numpy() for k, v in m.state_dict().items() if "running" in k}))
+        finally:
+            E.tune_set("enc_pconv_mfma", 0)
+    for i in (0, 1):
+        assert rel_err(outs[0][i], outs[1][i].astype(np.float64)) < 2e-6
+    for k, v in outs[1][2].items():
+        np.testing.assert_allclose(outs[0][2][k], v, rtol=1e-5, atol=1e-9, err_msg=k)
