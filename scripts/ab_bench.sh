@@ -6,7 +6,7 @@ for rep in 1 2; do
   for spec in "$@"; do
     label=${spec%%:*}; envs=${spec#*:}
     [ "$envs" = "$spec" ] && envs=""
-    env $envs python bench.py --gpus 1 --steps 20 --warmup 5 --no-secondary --no-cpu-baseline > "$out/$label.$rep.json" 2> "$out/$label.$rep.err" || echo "FAILED $label"
+    env $envs python bench.py --gpus 1 --steps 20 --warmup 5 --no-secondary --no-cpu-baseline $AB_ARGS > "$out/$label.$rep.json" 2> "$out/$label.$rep.err" || echo "FAILED $label"
     python - "$out/$label.$rep.json" "$label.$rep" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
