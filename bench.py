@@ -240,6 +240,7 @@ def measure_sorl_enc(steps, warmup, batch=512, angle_bins=360, dist_bins=256, en
     from porl_amd.agent.fasternet import FasterNet
     from porl_amd.agent.sorl import SORL
     from porl_amd import engine as E
+    _apply_tuning_env(E)
     dev = torch.device("cuda", torch.cuda.current_device())
     Bq, F, Hq, Aq = batch, 256, 512, 2
     torch.manual_seed(0)

@@ -776,7 +776,8 @@ __global__ void slab_reduce_kernel(float* __restrict__ out, const float* __restr
 // ---------------------------------------------------------------------------------------------------
 enum GemmMode : int { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_64x64 = 3,
-                      TILE_COUNT = 4 };
+                      TILE_128x96 = 4,     // N = 96 outputs (the encoder's stage-1 W2 product): no half-empty second column tile
+                      TILE_COUNT = 5 };
 
 constexpr int GEMM_BK = 32;
 
@@ -787,6 +788,7 @@ inline TileCfg tile_cfg(int tile) {
     case TILE_128x128: return {128, 128, 2, 2};
     case TILE_128x64: return {128, 64, 2, 2};
     case TILE_64x128: return {64, 128, 2, 2};
+    case TILE_128x96: return {128, 96, 4, 1};     // four waves of 32 x 96 (three accumulators each)
     default: return {64, 64, 2, 2};
   }
 }
@@ -844,7 +846,7 @@ inline hipError_t launch_tile(const GemmGroup& g, hipStream_t s) {
   if (apro) {
     // affine + ReLU prologue: instantiated for the two tiles the encoder's W2 products use, 16-byte operands,
     // forward layout, K a whole number of K-tiles (the column scale / shift are read unguarded)
-    if constexpr ((BM == 64 && BN == 64) || (BM == 128 && BN == 64)) {
+    if constexpr ((BM == 64 && BN == 64) || (BM == 128 && BN == 64) || (BM == 128 && BN == 96)) {
       for (int i = 0; i < g.nprob; ++i) {
         const GemmProb& p = g.p[i];
         if (!p.a_kc || !p.b_kc || p.K % GEMM_BK || p.splitk > 1 || !p.a_colscale || !p.a_colshift || !vec ||
@@ -872,6 +874,7 @@ inline hipError_t launch_gemm_group(int tile, GemmGroup& g, hipStream_t s) {
     case TILE_128x64: return launch_tile<128, 64, 2, 2>(g, s);
     case TILE_64x128: return launch_tile<64, 128, 2, 2>(g, s);
     case TILE_64x64: return launch_tile<64, 64, 2, 2>(g, s);
+    case TILE_128x96: return launch_tile<128, 96, 4, 1>(g, s);
   }
   return hipErrorInvalidValue;
 }

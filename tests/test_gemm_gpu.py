@@ -36,7 +36,7 @@ def _tol(K):
 
 
 @pytest.mark.parametrize("mode", ["NT", "NN", "TN"])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (256, 192, 1024), (100, 70, 60), (37, 300, 129), (1, 5, 3)])
 def test_gemm_plain(mode, tile, shape):
     M, N, K = shape
