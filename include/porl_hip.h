@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define PORL_ABI_VERSION 4
+#define PORL_ABI_VERSION 5
 #define PORL_MAX_HIDDEN 8
 
 #define PORL_OK 0
@@ -245,10 +245,33 @@ int porl_qr_loss(const float* z_cur, const float* z_next_online, const float* z_
                  int32_t n_quantiles, float gamma, float kappa, float* dz_out, float* row_loss, void* stream);
 /* IQN quantile-Huber loss head only (src/porl/train/iqn_trainer.py:136-149): current (batch, n_current) quantile values
  * of the taken actions at fractions taus (batch, n_current), target (batch, n_target) Bellman targets; dcurrent_out =
- * dL/dcurrent for loss = mean_b row_loss[b].  (Upstream's IQNTrainer / IQNNetwork pair cannot run as shipped, so there is
- * no learn() to mirror.) */
+ * dL/dcurrent for loss = mean_b row_loss[b].  (Upstream's IQNTrainer / IQNNetwork pair cannot run as shipped:
+ * porl_amd/train/iqn_trainer.py states how learn() is read.) */
 int porl_iqn_quantile_huber(const float* current, const float* target, const float* taus, int32_t batch, int32_t n_current,
                             int32_t n_target, float kappa, float* dcurrent_out, float* row_loss, void* stream);
+/* The parts of an Implicit Quantile Network step that are not Linear layers (src/porl/net/iqn_network.py:35-91,
+ * src/porl/train/iqn_trainer.py:92-134; csrc/iqn.hpp).  Row-major fp32, `n_tau` quantile fractions per sample.
+ *   cos_embed        out (n, E): cos(pi * i * taus[r]), i = 1..E                                   iqn_network.py:74-91
+ *   hadamard         out (batch*n_tau, H) = feat[b, :] (row stride ldf) * emb (batch*n_tau, H)     iqn_network.py:58-62
+ *   hadamard_backward  dfeat (batch, H) = sum_n dout * emb, demb = dout * feat; either may be null
+ *   select / scatter   out (batch, n_tau) = z[b, n, actions[b]] and its adjoint dz (batch, n_tau, A) iqn_trainer.py:101-103
+ *   target           a* = argmax_a mean_n z_online_next[b, n, a]; td (batch, n_tau) = r + gamma * z_target_next[b, n, a*] *
+ *                    (1 - done); next_actions (batch,) optional                                     iqn_trainer.py:108-121 */
+int porl_iqn_cos_embed(const float* taus, int64_t n, int32_t embedding_dim, float* out, void* stream);
+int porl_iqn_hadamard(const float* feat, int64_t ldf, const float* emb, int32_t batch, int32_t n_tau, int32_t width,
+                      float* out, void* stream);
+int porl_iqn_hadamard_backward(const float* dout, const float* feat, int64_t ldf, const float* emb, int32_t batch,
+                               int32_t n_tau, int32_t width, float* dfeat, float* demb, void* stream);
+int porl_iqn_select(const float* z, const int64_t* actions, int32_t batch, int32_t n_tau, int32_t n_actions, float* out,
+                    void* stream);
+int porl_iqn_scatter(const float* dsel, const int64_t* actions, int32_t batch, int32_t n_tau, int32_t n_actions, float* dz,
+                     void* stream);
+int porl_iqn_target(const float* z_online_next, const float* z_target_next, const float* rewards, const float* dones,
+                    float gamma, int32_t batch, int32_t n_tau, int32_t n_actions, float* td, int64_t* next_actions,
+                    void* stream);
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) on one flat gradient buffer (iqn_trainer.py:131): norm_coef[0] = the
+ * total 2-norm, norm_coef[1] = min(1, max_norm / (norm + 1e-6)), grads scaled in place.  workspace: >= 256 doubles. */
+int porl_grad_clip(float* grads, int64_t n, float max_norm, float* norm_coef, double* workspace, void* stream);
 /* C51 projection + cross-entropy (src/porl/train/c51_trainer.py:52-174) on PRE-softmax outputs (the log_softmax of
  * categorical_q_network.py:76-78 is applied inside, to both networks' rows). */
 int porl_c51_loss(const float* logits_cur, const float* logits_next_target, int64_t ld, const int64_t* actions,

@@ -760,6 +760,70 @@ def gen_iqn_loss(name, B=37, NP=8, NPP=11, kappa=0.7, seed=19):
     print(f"{name}: loss={loss.item()}")
 
 
+def gen_iqn(name, S=9, A=5, E=16, H=64, B=48, K=4, NP=8, NPP=6, seed_model=9, seed_data=43, seed_rand=23, gamma=0.97,
+            kappa=0.6, lr=5e-4):
+    """IQNNetwork.forward (src/porl/net/iqn_network.py:35-72) on the LIVE class of that file, and IQNTrainer.learn
+    (src/porl/train/iqn_trainer.py:92-134) — upstream's own method, unmodified — on a hand-built trainer: the constructor
+    cannot run (it passes five arguments to a four-argument network class, :58-72), and learn calls `get_q_values`, which the
+    live class lacks, so each network instance gets `get_q_values` bound to its own forward (the one reading under which
+    lines 92-134 type-check: (B, N, action) quantile values).  Minibatches are fixed (a stub replay buffer hands them out in
+    order); the fractions are torch.rand draws after torch.manual_seed(seed_rand + k), regenerated here for the fixture.
+    Rewards are scaled by 3 so both Huber branches occur; the target net differs from the online net."""
+    _stub_cql_imports()
+    from porl.train.iqn_trainer import IQNTrainer
+    from porl.net.iqn_network import IQNNetwork
+    dev = torch.device("cpu")
+    torch.manual_seed(seed_model)
+    t = object.__new__(IQNTrainer)
+    t.q_network = IQNNetwork(S, A, E, H)
+    t.target_network = IQNNetwork(S, A, E, H)
+    t.target_network.load_state_dict(t.q_network.state_dict())
+    with torch.no_grad():
+        for p in t.target_network.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    for net in (t.q_network, t.target_network):
+        net.get_q_values = net.forward
+    t.optimizer = torch.optim.Adam(t.q_network.parameters(), lr=lr)
+    t.batch_size, t.gamma, t.device, t.kappa = B, gamma, dev, kappa
+    t.num_quantiles_n_prime_loss, t.num_quantiles_n_double_prime_loss = NP, NPP
+    st, ac, rw, ns, dn = make_discrete_transitions(B * K, S, A, seed=seed_data)
+    rw = (3.0 * rw).astype(np.float32)
+
+    class _Replay:
+        k = 0
+        def sample(self, batch_size):
+            i = slice(self.k * batch_size, (self.k + 1) * batch_size)
+            self.k += 1
+            return (torch.from_numpy(st[i]), torch.from_numpy(ac[i]).long(), torch.from_numpy(rw[i]),
+                    torch.from_numpy(ns[i]), torch.from_numpy(dn[i].astype(np.float32)))
+    t.replay_buffer = _Replay()
+    out = {"meta": np.array([S, A, E, H, B, K, NP, NPP, seed_model, seed_data, seed_rand]), "gamma": np.float64(gamma),
+           "kappa": np.float64(kappa), "lr": np.float64(lr), "states": st, "actions": ac.astype(np.int64), "rewards": rw,
+           "next_states": ns, "dones": dn.astype(np.float32)}
+    out.update(pack("init/", sd_np(t.q_network)))
+    out.update(pack("init_target/", sd_np(t.target_network)))
+    # forward golden on the initial network
+    g = torch.Generator().manual_seed(seed_rand - 1)
+    probe_taus = torch.rand(7, 5, generator=g)
+    with torch.no_grad():
+        out["probe_x"] = st[:7]
+        out["probe_taus"] = probe_taus.numpy()
+        out["probe_z"] = t.q_network(torch.from_numpy(st[:7]), probe_taus).numpy()
+        out["probe_embed"] = t.q_network.get_quantile_embedding(probe_taus).numpy()
+    losses, tp, tpp = [], [], []
+    for k in range(K):
+        torch.manual_seed(seed_rand + k)
+        tp.append(torch.rand(B, NP).numpy())
+        tpp.append(torch.rand(B, NPP).numpy())
+        torch.manual_seed(seed_rand + k)
+        losses.append(IQNTrainer.learn(t))
+    out["loss"] = np.array(losses, dtype=np.float64)
+    out["taus_prime"], out["taus_double_prime"] = np.stack(tp), np.stack(tpp)
+    out.update(pack("final/", sd_np(t.q_network)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={losses}")
+
+
 def sub_dict(d, prefix):
     return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
 
@@ -768,7 +832,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     if len(sys.argv) > 1:                      # `gen_golden.py dddqn`: (re)generate one fixture family only
-        {"dddqn": lambda: gen_dddqn("dddqn_s10_a6")}[sys.argv[1]]()
+        {"dddqn": lambda: gen_dddqn("dddqn_s10_a6"), "iqn": lambda: gen_iqn("iqn_s9_a5")}[sys.argv[1]]()
         return
     # POR — small, fully stored
     gen_por("por_s60_h64_b32", S=60, H=64, L=2, layer_norm=False, B=32, K=5, full=True)
@@ -805,6 +869,7 @@ def main():
     gen_qr("qrdqn_s9_a5_n12")
     gen_c51("c51_s9_a5_n21")
     gen_iqn_loss("iqn_quantile_huber")
+    gen_iqn("iqn_s9_a5")
 
 
 if __name__ == "__main__":

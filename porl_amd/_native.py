@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libporl_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/porl_hip.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
@@ -27,7 +27,7 @@ SYMBOLS = [
     "porl_qnet_create", "porl_qnet_destroy", "porl_qnet_param_floats", "porl_qnet_tensors",
     "porl_qnet_tensor_info", "porl_qnet_workspace_floats", "porl_qnet_bind", "porl_qnet_load_batch",
     "porl_qnet_cql_backward", "porl_qnet_apply", "porl_qnet_learn", "porl_qnet_sync_target",
-    "porl_qnet_forward", "porl_qnet_forward_loaded", "porl_qnet_backward", "porl_qr_loss", "porl_iqn_quantile_huber", "porl_c51_loss", "porl_reduce_mean", "porl_qnet_penalty", "porl_qnet_learn_indexed", "porl_qnet_one_launch", "porl_qnet_learn_variant", "porl_qnet_can_sample", "porl_qnet_learn_sampled",
+    "porl_qnet_forward", "porl_qnet_forward_loaded", "porl_qnet_backward", "porl_qr_loss", "porl_iqn_quantile_huber", "porl_iqn_cos_embed", "porl_iqn_hadamard", "porl_iqn_hadamard_backward", "porl_iqn_select", "porl_iqn_scatter", "porl_iqn_target", "porl_grad_clip", "porl_c51_loss", "porl_reduce_mean", "porl_qnet_penalty", "porl_qnet_learn_indexed", "porl_qnet_one_launch", "porl_qnet_learn_variant", "porl_qnet_can_sample", "porl_qnet_learn_sampled",
     "porl_enc_create", "porl_enc_destroy", "porl_enc_param_floats", "porl_enc_stat_floats",
     "porl_enc_workspace_floats", "porl_enc_tensors", "porl_enc_norms", "porl_enc_blocks",
     "porl_enc_tensor_info", "porl_enc_norm_info", "porl_enc_bind", "porl_enc_weights_changed", "porl_enc_forward",
@@ -165,6 +165,13 @@ def _declare(lib):
     lib.porl_c51_loss.argtypes = [vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, vp, vp, vp]
     lib.porl_reduce_mean.argtypes = [vp, i32, vp, vp]
     lib.porl_iqn_quantile_huber.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp]
+    lib.porl_iqn_cos_embed.argtypes = [vp, i64, i32, vp, vp]
+    lib.porl_iqn_hadamard.argtypes = [vp, i64, vp, i32, i32, i32, vp, vp]
+    lib.porl_iqn_hadamard_backward.argtypes = [vp, vp, i64, vp, i32, i32, i32, vp, vp, vp]
+    lib.porl_iqn_select.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.porl_iqn_scatter.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.porl_iqn_target.argtypes = [vp, vp, vp, vp, f32, i32, i32, i32, vp, vp, vp]
+    lib.porl_grad_clip.argtypes = [vp, i64, f32, vp, vp, vp]
     lib.porl_qnet_penalty.argtypes = [vp, vp, i64, vp, i64, i32, vp, vp]
     lib.porl_enc_create.argtypes = [C.POINTER(EncCfg), C.POINTER(vp)]
     lib.porl_enc_destroy.argtypes = [vp]

@@ -16,6 +16,7 @@
 #include "kernels.hpp"
 #include "l0_fwd.hpp"
 #include "skinny.hpp"
+#include "iqn.hpp"
 #include "qnet_fused.hpp"
 #include "per_tree.hpp"
 #include "dist_losses.hpp"
@@ -2113,6 +2114,102 @@ int porl_iqn_quantile_huber(const float* current, const float* target, const flo
   IqnLossArgs a{current, target, taus, dcurrent_out, row_loss, batch, n_current, n_target, kappa, 1.0f / batch};
   hipLaunchKernelGGL(iqn_loss_kernel, dim3(cdiv(batch, 4)), dim3(256), 0, (hipStream_t)stream, a);
   PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+namespace {
+inline unsigned iqn_blocks(long items) { return (unsigned)std::min<long>(std::max<long>((items + 255) / 256, 1), 256L * 16); }
+inline int iqn_dims_ok(int32_t batch, int32_t n_tau, int32_t third) {
+  if (batch < 1 || n_tau < 1 || third < 1) PORL_FAIL(PORL_ERR_INVALID, "batch %d, n_tau %d, width/actions %d must be >= 1", batch, n_tau, third);
+  if ((int64_t)batch * n_tau * third > (int64_t)1 << 40) PORL_FAIL(PORL_ERR_INVALID, "tensor too large");
+  return PORL_OK;
+}
+}  // namespace
+
+int porl_iqn_cos_embed(const float* taus, int64_t n, int32_t embedding_dim, float* out, void* stream) {
+  if (!taus || !out) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  if (n < 1 || embedding_dim < 1 || n > ((int64_t)1 << 40) / embedding_dim) PORL_FAIL(PORL_ERR_INVALID, "n %lld, embedding_dim %d", (long long)n, embedding_dim);
+  DevGuard _dg(device_of(out));
+  hipLaunchKernelGGL(iqn_cos_embed_kernel, dim3(iqn_blocks(n * embedding_dim)), dim3(256), 0, (hipStream_t)stream, taus, (long)n,
+                     embedding_dim, out);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_iqn_hadamard(const float* feat, int64_t ldf, const float* emb, int32_t batch, int32_t n_tau, int32_t width,
+                      float* out, void* stream) {
+  if (!feat || !emb || !out) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  PORL_TRY(iqn_dims_ok(batch, n_tau, width));
+  if (ldf < width) PORL_FAIL(PORL_ERR_INVALID, "feature row stride %lld < width %d", (long long)ldf, width);
+  const bool al = !((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(out)) & 15u);
+  DevGuard _dg(device_of(out));
+  hipLaunchKernelGGL(iqn_hadamard_kernel, dim3(iqn_blocks((long)batch * n_tau * width / 4)), dim3(256), 0, (hipStream_t)stream,
+                     feat, (long)ldf, emb, batch, n_tau, width, out, al ? 1 : 0);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_iqn_hadamard_backward(const float* dout, const float* feat, int64_t ldf, const float* emb, int32_t batch,
+                               int32_t n_tau, int32_t width, float* dfeat, float* demb, void* stream) {
+  if (!dout || !feat || !emb || (!dfeat && !demb)) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  PORL_TRY(iqn_dims_ok(batch, n_tau, width));
+  if (ldf < width) PORL_FAIL(PORL_ERR_INVALID, "feature row stride %lld < width %d", (long long)ldf, width);
+  DevGuard _dg(device_of(dout));
+  hipLaunchKernelGGL(iqn_hadamard_bwd_kernel, dim3(iqn_blocks((long)batch * width)), dim3(256), 0, (hipStream_t)stream, dout,
+                     feat, (long)ldf, emb, batch, n_tau, width, dfeat, demb);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_iqn_select(const float* z, const int64_t* actions, int32_t batch, int32_t n_tau, int32_t n_actions, float* out,
+                    void* stream) {
+  if (!z || !actions || !out) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  PORL_TRY(iqn_dims_ok(batch, n_tau, n_actions));
+  DevGuard _dg(device_of(out));
+  hipLaunchKernelGGL(iqn_select_kernel, dim3(iqn_blocks((long)batch * n_tau)), dim3(256), 0, (hipStream_t)stream, z, actions,
+                     batch, n_tau, n_actions, out);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_iqn_scatter(const float* dsel, const int64_t* actions, int32_t batch, int32_t n_tau, int32_t n_actions, float* dz,
+                     void* stream) {
+  if (!dsel || !actions || !dz) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  PORL_TRY(iqn_dims_ok(batch, n_tau, n_actions));
+  DevGuard _dg(device_of(dz));
+  hipLaunchKernelGGL(iqn_scatter_kernel, dim3(iqn_blocks((long)batch * n_tau * n_actions)), dim3(256), 0, (hipStream_t)stream,
+                     dsel, actions, batch, n_tau, n_actions, dz);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_iqn_target(const float* z_online_next, const float* z_target_next, const float* rewards, const float* dones,
+                    float gamma, int32_t batch, int32_t n_tau, int32_t n_actions, float* td, int64_t* next_actions,
+                    void* stream) {
+  if (!z_online_next || !z_target_next || !rewards || !dones || !td) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  PORL_TRY(iqn_dims_ok(batch, n_tau, n_actions));
+  DevGuard _dg(device_of(td));
+  hipLaunchKernelGGL(iqn_target_kernel, dim3(iqn_blocks(batch)), dim3(256), 0, (hipStream_t)stream, z_online_next,
+                     z_target_next, rewards, dones, gamma, batch, n_tau, n_actions, td, next_actions);
+  PORL_HIP(hipGetLastError());
+  return PORL_OK;
+}
+
+int porl_grad_clip(float* grads, int64_t n, float max_norm, float* norm_coef, double* workspace, void* stream) {
+  if (!grads || !norm_coef || !workspace) PORL_FAIL(PORL_ERR_INVALID, "null argument");
+  if (n < 0 || n > (int64_t)1 << 40) PORL_FAIL(PORL_ERR_INVALID, "n = %lld", (long long)n);
+  if (!(max_norm > 0.f)) PORL_FAIL(PORL_ERR_INVALID, "max_norm must be positive");
+  DevGuard _dg(device_of(grads));
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = (int)std::min<long>(CLIP_BLOCKS, std::max<long>(1, (n + 4095) / 4096));
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, grads, (long)n, workspace);
+  PORL_HIP(hipGetLastError());
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, s, workspace, nb, max_norm, norm_coef);
+  PORL_HIP(hipGetLastError());
+  if (n > 0) {
+    hipLaunchKernelGGL(scale_by_kernel, dim3(iqn_blocks(n)), dim3(256), 0, s, grads, (long)n, norm_coef);
+    PORL_HIP(hipGetLastError());
+  }
   return PORL_OK;
 }
 

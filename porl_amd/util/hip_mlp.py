@@ -59,6 +59,8 @@ class _MlpFn(torch.autograd.Function):
         dz = dy.contiguous()
         if ctx.out_act == 2:
             dz = dz * (1.0 - acts[-1] * acts[-1])                    # tanh'(z) from the stored output
+        elif ctx.out_act == 1:
+            dz = dz * (acts[-1] > 0).to(dz.dtype)                    # a chain that ends in ReLU (IQN's feature_net)
         grads = [None] * (2 * n_lin)
         dx = None
         for l in range(n_lin - 1, -1, -1):
@@ -100,7 +102,8 @@ def mlp_forward(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
             raise NotImplementedError(f"{type(m).__name__} inside an mlp() chain is not on the device path")
     if h.shape[1] != lin[0].in_features:
         raise RuntimeError(f"expected (..., {lin[0].in_features}), got {tuple(x.shape)}")
-    out_act = 2 if isinstance([m for m in seq if not isinstance(m, Squeeze)][-1], nn.Tanh) else 0
+    last = [m for m in seq if not isinstance(m, Squeeze)][-1]
+    out_act = 2 if isinstance(last, nn.Tanh) else 1 if isinstance(last, nn.ReLU) else 0
     params = []
     for m in lin:
         if m.weight.device != x.device:

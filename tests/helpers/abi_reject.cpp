@@ -128,6 +128,21 @@ int main() {
   REJECT(porl_qr_loss(x, x, x, 8, reinterpret_cast<int64_t*>(P[0]), x, x, 4, 2, 100000, 0.99f, 1.f, x, x, nullptr));
   REJECT(porl_c51_loss(x, x, 8, reinterpret_cast<int64_t*>(P[0]), x, x, x, 4, 2, 100000, 0.99f, -1.f, 1.f, x, x, nullptr));
   REJECT(porl_iqn_quantile_huber(nullptr, x, x, 4, 4, 4, 1.f, x, x, nullptr));
+  REJECT(porl_iqn_cos_embed(nullptr, 4, 8, x, nullptr));
+  REJECT(porl_iqn_cos_embed(x, 0, 8, x, nullptr));
+  REJECT(porl_iqn_cos_embed(x, (int64_t)1 << 41, 8, x, nullptr));
+  REJECT(porl_iqn_hadamard(x, 4, x, 2, 2, 8, x, nullptr));                 // row stride below the width
+  REJECT(porl_iqn_hadamard(x, 8, nullptr, 2, 2, 8, x, nullptr));
+  REJECT(porl_iqn_hadamard_backward(x, x, 8, x, 2, 2, 8, nullptr, nullptr, nullptr));   // neither output
+  REJECT(porl_iqn_hadamard_backward(x, x, 8, x, 0, 2, 8, x, x, nullptr));
+  REJECT(porl_iqn_select(x, nullptr, 2, 2, 3, x, nullptr));
+  REJECT(porl_iqn_select(x, reinterpret_cast<int64_t*>(P[0]), 2, 0, 3, x, nullptr));
+  REJECT(porl_iqn_scatter(x, reinterpret_cast<int64_t*>(P[0]), 2, 2, 0, x, nullptr));
+  REJECT(porl_iqn_target(x, x, x, nullptr, 0.9f, 2, 2, 3, x, nullptr, nullptr));
+  REJECT(porl_iqn_target(x, x, x, x, 0.9f, -1, 2, 3, x, nullptr, nullptr));
+  REJECT(porl_grad_clip(x, 8, 0.f, x, reinterpret_cast<double*>(P[0]), nullptr));      // max_norm must be positive
+  REJECT(porl_grad_clip(x, -1, 1.f, x, reinterpret_cast<double*>(P[0]), nullptr));
+  REJECT(porl_grad_clip(x, 8, 1.f, x, nullptr, nullptr));
   REJECT(porl_gemm_f32(7, -1, 8, 8, 8, x, 8, x, 8, x, 8, nullptr, 0, nullptr, 0, 1, nullptr, nullptr));
   REJECT(porl_gemm_f32(0, -1, 8, 8, 8, nullptr, 8, x, 8, x, 8, nullptr, 0, nullptr, 0, 1, nullptr, nullptr));
   REJECT(porl_tune_set(nullptr, 1));

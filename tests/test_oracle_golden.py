@@ -206,3 +206,24 @@ def test_torch_cpu_baseline_restatements_agree_with_the_oracle():
         want = co.learn(st[sl], ac[sl], rw[sl], ns[sl], dn[sl])
         got = ct.learn(*(torch.from_numpy(x[sl]) for x in (st, ac, rw, ns, dn)))
         np.testing.assert_allclose(got, want if np.isscalar(want) else want[0], rtol=2e-5)
+
+
+# ---- Implicit Quantile Network (oracle/iqn_oracle.py) ---------------------------------------------------
+def test_iqn_oracle_matches_reference_golden():
+    """Forward of the reference's live IQNNetwork and four steps of upstream's own IQNTrainer.learn (fixture:
+    oracle/gen_golden.py:gen_iqn) against the numpy restatement."""
+    from oracle import iqn_oracle as IO
+    z = np.load(os.path.join(REPO, "tests", "golden", "iqn_s9_a5.npz"), allow_pickle=False)
+    S, A, E, H, B, K, NP, NPP = (int(v) for v in z["meta"][:8])
+    init = {k: v.astype(np.float64) for k, v in sub(z, "init/").items()}
+    np.testing.assert_allclose(IO.cos_embed(z["probe_taus"].astype(np.float64), E), z["probe_embed"], atol=2e-5)
+    np.testing.assert_allclose(IO.forward(init, z["probe_x"].astype(np.float64), z["probe_taus"].astype(np.float64)),
+                               z["probe_z"], atol=1e-5)
+    o = IO.IqnOracle(sub(z, "init/"), sub(z, "init_target/"), gamma=float(z["gamma"]), kappa=float(z["kappa"]),
+                     lr=float(z["lr"]))
+    for k in range(K):
+        i = slice(k * B, (k + 1) * B)
+        loss = o.learn(z["states"][i], z["actions"][i], z["rewards"][i], z["next_states"][i], z["dones"][i],
+                       z["taus_prime"][k], z["taus_double_prime"][k])
+        np.testing.assert_allclose(loss, z["loss"][k], rtol=LOSS_RTOL)
+    _assert_params(o.P, sub(z, "final/"))
