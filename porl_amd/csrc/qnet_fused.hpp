@@ -354,6 +354,97 @@ __device__ __forceinline__ void qf_loss_rows(const QnetFusedArgs& a, const float
   }
 }
 
+// ---- the same stage on 256 lanes: EIGHT lanes per row (round 3) --------------------------------------------------
+// One lane per row spends ~5 k cycles in two expf per action (12 columns x 2 x ~35 instructions, one wave, seven
+// other waves waiting at the barrier).  Here thread t of the first four waves takes row t / 8 and the actions
+// sub, sub + 8, sub + 16, sub + 24 (sub = t % 8; A <= 32): one or two expf per lane, row-wide maximum / sum / picks as
+// three-step butterflies over the 8 lanes on the DPP path (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror: no LDS
+// traffic).  A butterfly leaves the SAME bits in all 8 lanes (each step adds the same two values in either order), so
+// every lane can form the row's target / weight terms itself.  Against the one-lane form the row sum is associated as
+// a tree instead of left to right: results agree to rounding (tests/test_cql_gpu.py compares the paths at 2e-6).
+// Rows' scalars (action, reward, done) arrive in the 8-lane mapping (act8 / rew8 / done8, requested at kernel entry).
+// The masked-argmax variant (BCQ) and A > 32 keep the one-lane form.
+template <int CTRL> __device__ __forceinline__ float qf_dpp(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float qf_sum8(float x) {
+  x += qf_dpp<0xB1>(x);
+  x += qf_dpp<0x4E>(x);
+  x += qf_dpp<0x141>(x);
+  return x;
+}
+__device__ __forceinline__ float qf_max8(float x) {
+  x = fmaxf(x, qf_dpp<0xB1>(x));
+  x = fmaxf(x, qf_dpp<0x4E>(x));
+  x = fmaxf(x, qf_dpp<0x141>(x));
+  return x;
+}
+__device__ __forceinline__ bool qf_loss_wide_ok(const QnetFusedArgs& a) { return a.dims[a.n_lin] <= 32 && !a.next_mask; }
+
+// t: thread number among the 256 that run the stage (four whole waves); red: >= 8 floats (per-wave partial sums)
+__device__ __forceinline__ void qf_loss_rows8(const QnetFusedArgs& a, const float* Q, const float* Qn, float* dz, const int* amax,
+                                              int act8, float rew8, float done8, int row0, int t, float* red, int rows) {
+  const int A = a.dims[a.n_lin], ldq = qf_r32(A) + 4;          // 36
+  const int r = t >> 3, sub = t & 7;
+  const int b = row0 + r;
+  const bool live = r < rows && b < a.B;
+  const int rr = r < rows ? r : 0;
+  const float* q = Q + rr * ldq;
+  const float* qn = Qn + rr * ldq;
+  float qv[4], nv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = sub + 8 * k;
+    qv[k] = j < A ? q[j] : -INFINITY;
+    nv[k] = j < A ? qn[j] : -INFINITY;
+  }
+  const float mx = qf_max8(fmaxf(fmaxf(qv[0], qv[1]), fmaxf(qv[2], qv[3])));
+  const float mxn = qf_max8(fmaxf(fmaxf(nv[0], nv[1]), fmaxf(nv[2], nv[3])));
+  float se = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (sub + 8 * k < A) se += expf(qv[k] - mx);
+  se = qf_sum8(se);
+  const float lse = mx + logf(se);
+  float qa = 0.f, qpick = 0.f;
+  const int am = a.double_dqn ? amax[rr] : -1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = sub + 8 * k;
+    qa += (j == act8 && j < A) ? qv[k] : 0.f;                   // exactly one lane of the row adds a non-zero term
+    qpick += (j == am && j < A) ? nv[k] : 0.f;
+  }
+  qa = qf_sum8(qa);
+  qpick = qf_sum8(qpick);
+  const float qnext = a.double_dqn ? qpick : mxn;
+  const float y = rew8 + a.gamma * qnext * (1.f - done8);
+  const float diff = a.td_off ? 0.f : qa - y;
+  float wgt = (a.is_w && live) ? a.is_w[b] : 1.f;
+  if (a.w_uniform) wgt *= a.w_uniform[0];
+  const float td = wgt * (diff * diff);
+  const float pen = lse - a.log_A - qa;
+  if (a.td_abs && live && sub == 0) a.td_abs[b] = fabsf(diff);
+  const float ab = a.alpha * a.inv_batch;
+  if (r < rows) {
+    float* dq = dz + r * ldq;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {                               // the whole 36-float row: dL/dQ, then zeros
+      const int j = sub + 8 * k;
+      if (j < ldq) {
+        float g = 0.f;
+        if (k < 4 && j < A && live) {
+          g = ab * expf(qv[k < 4 ? k : 0] - lse);
+          if (j == act8) g += 2.f * a.inv_batch * wgt * diff - ab;
+        }
+        dq[j] = g;
+      }
+    }
+  }
+  float std_ = (live && sub == 0) ? td : 0.f, spen = (live && sub == 0) ? pen : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { std_ += __shfl_xor(std_, o); spen += __shfl_xor(spen, o); }
+  if ((t & 63) == 0) { red[2 * (t >> 6)] = std_; red[2 * (t >> 6) + 1] = spen; }
+}
+
 // dW_l = dZ^T . in over the block's 32 rows (32 x 32 tiles of (n, k), dealt over `nw` waves, wave id `w`) and db_l =
 // column sums of dZ (over `nt` threads, thread id `t`), written to the block's slab in the flat parameter layout.
 // A tile's 32 + 32 fragment values are all requested before its 16 MFMAs (one LDS round trip per tile, not four).
@@ -444,7 +535,7 @@ __device__ __forceinline__ void qf_dgrad(const float* dz, int lddz, const float*
 
 __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) {
   extern __shared__ float qf_lds[];
-  __shared__ float red[2];
+  __shared__ float red[8];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, kh = lane >> 5;
   const int row0 = blockIdx.x * QF_ROWS;
   const int L = a.n_lin - 1;
@@ -493,6 +584,11 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
   const long my_src = my_row < a.B ? (a.idx ? a.idx[my_row] : (long)my_row) : 0L;
   const int row_act = (int)a.actions[my_src];
   const float row_rew = a.rew[my_src], row_done = a.done[my_src];
+  // the same in the 8-lanes-per-row mapping of qf_loss_rows8 (thread t -> row t / 8)
+  const int my_row8 = row0 + (t >> 3);
+  const long my_src8 = my_row8 < a.B ? (a.idx ? a.idx[my_row8] : (long)my_row8) : 0L;
+  const int act8 = (int)a.actions[my_src8];
+  const float rew8 = a.rew[my_src8], done8 = a.done[my_src8];
 
   // ---- target network on s'  (cql_trainer.py:99-101) ---------------------------------------------------
   // s' waits in tmp[1] (free until the target net's layer 1 writes there), s in the online net's input buffer
@@ -529,9 +625,14 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
 
   stamp();
   // ---- loss and dL/dQ: one lane per row  (cql_trainer.py:94-118; same arithmetic as cql_loss_kernel) ----
-  qf_loss_rows(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, row_act, row_rew, row_done, row0, lane, wave, red);
+  const bool wide = qf_loss_wide_ok(a);
+  if (wide) qf_loss_rows8(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, act8, rew8, done8, row0, t, red, QF_ROWS);
+  else qf_loss_rows(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, row_act, row_rew, row_done, row0, lane, wave, red);
   qf_barrier();
-  if (t == 0) { a.part_td[blockIdx.x] = red[0]; a.part_pen[blockIdx.x] = red[1]; }
+  if (t == 0) {
+    a.part_td[blockIdx.x] = wide ? ((red[0] + red[2]) + red[4]) + red[6] : red[0];
+    a.part_pen[blockIdx.x] = wide ? ((red[1] + red[3]) + red[5]) + red[7] : red[1];
+  }
   stamp();
 
   // ---- backward, top down ----------------------------------------------------------------------------------
@@ -765,7 +866,7 @@ __device__ __forceinline__ void qf16_wgrad(const QnetFusedArgs& a, int l, const 
 template <int ROWS>
 __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a, int lds_w2) {
   extern __shared__ float qf_lds[];
-  __shared__ float red[2];
+  __shared__ float red[8];
   __shared__ int amax[QF_ROWS];
   const int t = threadIdx.x, grp = t >> 8, tg = t & 255, lane = t & 63, li = lane & 31, kh = lane >> 5;
   // A block's waves are dealt to the SIMDs in the order 0,2,1,3,0,2,1,3: wave w of group 0 and wave w of group 1 share
@@ -846,6 +947,11 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
   qf_input_load(xin, ldx, grp ? a.states : a.next_states, grp ? a.s_rs : a.n_rs, row0, a.B, a.dims[0], tg, ROWS);
   const int row_act = (int)a.actions[my_src];
   const float row_rew = a.rew[my_src], row_done = a.done[my_src];
+  // the same in the 8-lanes-per-row mapping of qf_loss_rows8 (thread tg of group 0 -> row tg / 8)
+  const int r8 = (tg >> 3) < ROWS ? (tg >> 3) : 0;
+  const long my_src8 = sampled ? srow[r8] : (row0 + r8 < a.B ? (a.idx ? a.idx[row0 + r8] : (long)(row0 + r8)) : 0L);
+  const int act8 = (int)a.actions[my_src8];
+  const float rew8 = a.rew[my_src8], done8 = a.done[my_src8];
   qf_input_store(xin, grp ? X : Xn, ldx, tg, ROWS);
   stamp();
 
@@ -889,9 +995,16 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
   // forward barrier, so group 0's forward buffer is dead — and lands while the loss is computed.
   auto bsel = [&](int l) __attribute__((always_inline)) { return ((L - l) & 1) ? wbuf0 : wbuf1; };
   if (grp == 0 && L > 1) dma(L + 2, bsel(L - 1));
-  if (grp == 0) qf_loss_rows(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, row_act, row_rew, row_done, row0, lane, wave, red, ROWS);
+  const bool wide = qf_loss_wide_ok(a);
+  if (grp == 0) {
+    if (wide) qf_loss_rows8(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, act8, rew8, done8, row0, tg, red, ROWS);
+    else qf_loss_rows(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, row_act, row_rew, row_done, row0, lane, wave, red, ROWS);
+  }
   if (grp == 0) barrier_vm(); else qf_barrier();
-  if (t == 0) { a.part_td[blockIdx.x] = red[0]; a.part_pen[blockIdx.x] = red[1]; }
+  if (t == 0) {
+    a.part_td[blockIdx.x] = wide ? ((red[0] + red[2]) + red[4]) + red[6] : red[0];
+    a.part_pen[blockIdx.x] = wide ? ((red[1] + red[3]) + red[5]) + red[7] : red[1];
+  }
   stamp();
 
   // ---- backward, top down: group 0 = dZ chain (+ requests the weights two layers down), group 1 = dW / db ---------
