@@ -142,6 +142,7 @@ def measure_cql(steps, warmup, with_cpu=True):
     from porl_amd.train.cql_trainer import CQLTrainer
     from porl_amd.util.synth import make_discrete_transitions
     from porl_amd import engine as E
+    _apply_tuning_env(E)
     dev = torch.device("cuda", torch.cuda.current_device())
     Sq, Aq, Bq, Nq = 60, 10, 4096, 100_000
     torch.manual_seed(0)
