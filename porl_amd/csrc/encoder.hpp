@@ -186,17 +186,20 @@ __global__ __launch_bounds__(256) void patch_stats_kernel(const float* __restric
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void patch_bn_kernel(const float* __restrict__ state, long state_rs, CostmapGeom g,
                                                        const float* __restrict__ w, int E, const float* __restrict__ alpha,
-                                                       const float* __restrict__ beta, float* __restrict__ out) {
+                                                       const float* __restrict__ beta, float* __restrict__ out, int rows_per_block) {
   extern __shared__ float ps_lds[];
   float* wl = ps_lds;
   unsigned long long* mask = reinterpret_cast<unsigned long long*>(ps_lds + PE_K * E);
   const int t = threadIdx.x, e4n = E >> 2, Wp = g.n_dist >> 2, Hp = g.n_ang >> 2;
-  const int py = blockIdx.x;
   const long b = blockIdx.y;
   for (int i = t; i < PE_K * E; i += 256) {
     const int e = i / PE_K, k = i - e * PE_K;
     wl[k * E + e] = w[i];
   }
+  // a block walks `rows_per_block` patch rows with the transposed weight parked once (small images: at 84x84 a patch
+  // row is 21 x 96 outputs, less work than parking the 18 KB weight)
+  for (int py = blockIdx.x * rows_per_block; py < (int)(blockIdx.x + 1) * rows_per_block && py < Hp; ++py) {
+  __syncthreads();                        // the previous row's masks are no longer read (first trip: the weight is parked)
   for (int i = t; i < Wp; i += 256) mask[i] = 0ull;
   __syncthreads();
   patch_row_masks(state + b * state_rs, g, py, mask, t);
@@ -221,6 +224,7 @@ __global__ __launch_bounds__(256) void patch_bn_kernel(const float* __restrict__
     } else {
       reinterpret_cast<float4*>(orow)[i] = o;
     }
+  }
   }
 }
 
