@@ -37,22 +37,24 @@ class _FlatAdam:
     """torch.optim.Adam's arithmetic (csrc: adam_ema_kernel) over ONE flat buffer holding every parameter of a module;
     the module's nn.Parameters and their .grad become views into the flat tensors."""
 
-    def __init__(self, module, lr, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, module, lr, betas=(0.9, 0.999), eps=1e-8, storage_only=False):
         ps = list(module.parameters())
         dev = ps[0].device
         ru4 = lambda k: (k + 3) // 4 * 4                  # every tensor starts on a 16-byte boundary (vector loads in the GEMM)
         n = sum(ru4(p.numel()) for p in ps)
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        m = 0 if storage_only else n                      # the target network only needs the flat parameter storage
+        self.grad = torch.zeros(m, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(m, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(m, dtype=torch.float32, device=dev)
         off = 0
         with torch.no_grad():
             for p in ps:
                 k = p.numel()
                 self.flat[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat[off:off + k].view_as(p)
-                p.grad = self.grad[off:off + k].view_as(p)
+                if not storage_only:
+                    p.grad = self.grad[off:off + k].view_as(p)
                 off += ru4(k)                                 # padding stays zero: its gradient is never written
         self.params = ps
         self.param_groups = [dict(params=ps, lr=lr, betas=betas, eps=eps)]
@@ -109,7 +111,7 @@ class IQNTrainer:
         self.q_network = IQNNetwork(state_size, action_size, embedding_dim, hidden_size).to(self.device)
         self.target_network = IQNNetwork(state_size, action_size, embedding_dim, hidden_size).to(self.device)
         self.optimizer = _FlatAdam(self.q_network, learning_rate)
-        self._target = _FlatAdam(self.target_network, learning_rate)          # flat storage only: never stepped
+        self._target = _FlatAdam(self.target_network, learning_rate, storage_only=True)
         for p in self.target_network.parameters():
             p.requires_grad_(False)
         self.sync_target()                                                     # target.load_state_dict(q.state_dict())
