@@ -602,6 +602,11 @@ def por_rank(a, force_dp):
             agent._engine.set_stats(losses[i])
             agent.update_from_replay(replay, B)
 
+        # set-up spin-up HERE, after the agent has been built (allocation and initialisation leave the card idle for
+        # ~0.1 s, long enough for it to fall back to its idle clocks): same-box comparison with scripts/bench_ramp.py,
+        # which spins right before its warm-up updates — 2 965-3 079 updates/s for K = 20 against 2 777-2 852 with the
+        # spin-up in front of the agent's construction (gpurun_out/r03/ramp)
+        spinup()
         for i in range(warmup):
             one_step(i)
         barrier()
@@ -666,7 +671,6 @@ def por_rank(a, force_dp):
     # -----------------------------------------------------------------------------------------------------------------
     if dp:
         modes = [m for m in (os.environ.get("PORL_BENCH_MODES") or ",".join(DP_MODES)).split(",") if m]
-        spinup()
         results = []
         for mode in modes:
             if inject == "die:" + mode and rank == world - 1:
@@ -698,7 +702,6 @@ def por_rank(a, force_dp):
         return
 
     # ---- N = 1 ------------------------------------------------------------------------------------------------------
-    spinup()
     mode = "one_stream" if a.no_pipeline else "pipelined"
     res = timed_run(mode, a.steps, a.warmup, keep=True)
     out = line_for(res, a.steps, a.warmup)
