@@ -707,10 +707,10 @@ def por_rank(a, force_dp):
     out = line_for(res, a.steps, a.warmup)
     agent, one_step = res["agent"], res["one_step"]
 
-    # Not `value`: the same loop again for 1 000 updates, five times, median.  After any idle the card needs ~10 ms of THIS
-    # workload to settle its clocks (scripts/bench_ramp.py: the first ~20 updates after a sync run 10 % slower, whatever
-    # GEMM or streaming spin-up precedes them), and a K = 20 run also pays the pipeline's fill and drain once; a training
-    # job runs millions of updates, so the sustained rate is reported beside the contract's K-step figure.
+    # Not `value`: the same loop again for 1 000 updates, five times, median.  The first ~20 updates after a device sync
+    # run ~4 % slower than the steady state (scripts/bench_ramp.py: 315 against 303 us each) and a K = 20 run also pays the
+    # pipeline's fill and drain (~0.3 ms) once; a training job runs millions of updates, so the sustained rate is reported
+    # beside the contract's K-step figure.
     if a.steps < 1000 and os.environ.get("PORL_BENCH_SUSTAINED", "1") != "0":
         n_s, rates = 1000, []
         for _ in range(5):
