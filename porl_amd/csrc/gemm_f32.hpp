@@ -79,6 +79,7 @@ constexpr int MAX_GROUP = 8;
 struct GemmGroup {
   int nprob;
   int total_blocks;
+  int single_buffer;      // the ONEBUF instantiation (64x64 tile, 16-byte operands): see gemm_f32_kernel
   GemmProb p[MAX_GROUP];
 };
 
@@ -142,7 +143,11 @@ __device__ unsigned long long g_stamps[16 * 4096];   // per block: entry, loop b
 //   APRO: A-operand prologue enabled (APRO_AFFINE_RELU) for every problem of the group (forward problems only).
 // Blocks whose tile lies completely inside the problem (and whose K range is a whole number of
 // K-tiles) take an unguarded main loop; edge blocks take the guarded one.
-template <int BM, int BN, int BK, int WM, int WN, bool VEC, bool APRO>
+//   ONEBUF: single LDS buffer + plain loop (request tile t+1, barrier, compute tile t, barrier, park t+1): half the LDS of
+//         the MFMA-paced schedule, so twice the co-resident blocks — for products with 3-6 K-tiles per block and
+//         millions of rows (the encoder's), where a block spends ~5 us getting its first operands and ~2.5 us storing
+//         C around 1.5-3 us of matrix work and only OTHER blocks can fill that.
+template <int BM, int BN, int BK, int WM, int WN, bool VEC, bool APRO, bool ONEBUF = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup g) {
   constexpr int THREADS = 64 * WM * WN;
   constexpr int WTM = BM / WM / 32;       // MFMA tiles per wave along M
@@ -167,8 +172,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
 
   // APRO: the (K,) column scale and shift of the operand prologue sit behind the staging buffers (read back with
   // one ds_read_b128 each when a slot is parked: no extra global loads, no extra registers in the MFMA loop)
-  constexpr int APRO_MAX_K = 1024;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE) + (APRO ? 2 * APRO_MAX_K : 0)];
+  constexpr int APRO_MAX_K = ONEBUF ? 512 : 1024;    // (the single-buffer form lives on co-resident blocks: 4 KB, not 8)
+  constexpr int NBUF = ONEBUF ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * (A_TILE + B_TILE) + (APRO ? 2 * APRO_MAX_K : 0)];
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
 
   // affine + ReLU prologue: the 4 elements of a slot of a k-contiguous A run along k, so a slot needs the scale and
   // shift of 4 consecutive columns (one 16-byte load each, issued with the operand request)
-  float* const apro_cs = lds + 2 * (A_TILE + B_TILE);      // [K] scale, then [K] shift at + APRO_MAX_K
+  float* const apro_cs = lds + NBUF * (A_TILE + B_TILE);      // [K] scale, then [K] shift at + APRO_MAX_K
   if constexpr (APRO) {
     for (int k = t; k < P.K; k += THREADS) { apro_cs[k] = P.a_colscale[k]; apro_cs[APRO_MAX_K + k] = P.a_colshift[k]; }
     // (made visible by the workgroup barrier that precedes the first use: store_tile of tile 0 runs before it, so
@@ -505,6 +511,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
       }
     };
 
+    if constexpr (ONEBUF) {
+      if (nkt > 0) load_tile(ktile(0));
+      if constexpr (APRO) __syncthreads();       // the scale / shift table in LDS is complete
+      for (int it = 0; it < nkt; ++it) {
+        if (it > 0) __syncthreads();             // every wave has read tile it-1 out of the buffer
+        store_tile(ktile(it), 0);                // (waits for the tile's loads)
+        if (it + 1 < nkt) load_tile(ktile(it + 1));
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+          for (int u = 0; u < NRU; ++u) read_unit(0, g, g & 1, u);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+              for (int n = 0; n < WTN; ++n)
+                acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][j], fb[g & 1][n][j], acc[i][n], 0, 0, 0);
+        }
+      }
+      __syncthreads();                           // the epilogue reuses the buffer for the C sub-tiles
+      return;
+    }
     if (nkt > 0) {
       load_tile(ktile(0));
       if constexpr (APRO) __syncthreads();       // the scale / shift table in LDS is complete
@@ -630,7 +660,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
   // last barrier of the main loop: nobody reads staged operands any more) and writes/reads C and the ReLU
   // mask in full 16-byte rows instead of one dword per lane.
   constexpr int WROWS = BM / WM, WCOLS = BN / WN, CS = WCOLS + 4;
-  static_assert(WM * WN * WROWS * CS <= 2 * (A_TILE + B_TILE), "C sub-tiles must fit in the staging LDS");
+  static_assert(WM * WN * WROWS * CS <= NBUF * (A_TILE + B_TILE), "C sub-tiles must fit in the staging LDS");
   const bool fast_c = store_c && P.c_vec && (m0 + BM <= M) && (n0 + BN <= N);
   float* ctile = lds + wave * (WROWS * CS);
 #pragma unroll
@@ -852,12 +882,24 @@ inline hipError_t launch_tile(const GemmGroup& g, hipStream_t s) {
         if (!p.a_kc || !p.b_kc || p.K % GEMM_BK || p.splitk > 1 || !p.a_colscale || !p.a_colshift || !vec ||
             (reinterpret_cast<uintptr_t>(p.a_colscale) & 15u) || (reinterpret_cast<uintptr_t>(p.a_colshift) & 15u))
           return hipErrorInvalidValue;
-        if (p.K > 1024) return hipErrorInvalidValue;          // APRO_MAX_K: the scale / shift table lives in LDS
+        if (p.K > (g.single_buffer && BM == 64 && BN == 64 ? 512 : 1024)) return hipErrorInvalidValue;   // APRO_MAX_K: the scale / shift table lives in LDS
+      }
+      if constexpr (BM == 64 && BN == 64) {
+        if (g.single_buffer) {
+          hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, true, true, true>), grid, block, pad, s, g);
+          return hipGetLastError();
+        }
       }
       hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, true, true>), grid, block, pad, s, g);
       return hipGetLastError();
     } else {
       return hipErrorInvalidValue;
+    }
+  }
+  if constexpr (BM == 64 && BN == 64) {
+    if (vec && g.single_buffer) {
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, true, false, true>), grid, block, pad, s, g);
+      return hipGetLastError();
     }
   }
   if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, GEMM_BK, WM, WN, true, false>), grid, block, pad, s, g);

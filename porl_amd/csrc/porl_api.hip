@@ -108,7 +108,8 @@ struct ProfScope {
 const float* g_dbg_a_scale = nullptr; const float* g_dbg_a_shift = nullptr; const float* g_dbg_resid = nullptr;
 float* g_dbg_cstat = nullptr;
 unsigned long long* g_qnet_stamps = nullptr;   // porl_tune_set_ptr("qnet_stamps", device buffer of >= 32 u64)
-int g_enc_tile_n96 = 1;
+int g_enc_tile_n96 = 0;
+int g_enc_gemm_sb = 1;        // porl_tune_set("enc_gemm_sb", 0): the encoder's 64x64 row products on the double-buffered schedule (A/B)
 int g_enc_patch_rows = 0;     // porl_tune_set("enc_patch_rows", n): patch rows per block of patch_bn_kernel (0 = by grid size; A/B)
 int g_enc_s2d = 0;           // porl_tune_set("enc_s2d", 1): materialise the 2x2 patches before the merge GEMM (cross-check)
 // What pick_tile returns where its occupancy rule selects tile i (porl_tune_set("tile_map<i>", t) / "tile_map_short<i>").
@@ -1488,6 +1489,7 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "enc_dense_patch")) { g_enc_dense_patch = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_s2d")) { g_enc_s2d = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_patch_rows")) { g_enc_patch_rows = std::max(0, value); return PORL_OK; }
+  if (!strcmp(key, "enc_gemm_sb")) { g_enc_gemm_sb = value; return PORL_OK; }
   if (!strcmp(key, "enc_tile_n96")) { g_enc_tile_n96 = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_bn_sweep")) { g_enc_bn_sweep = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_pconv_mfma")) { g_enc_pconv_mfma = value != 0; return PORL_OK; }

@@ -419,3 +419,38 @@ def test_partial_conv_on_the_matrix_pipe_agrees_with_the_direct_kernel(n_ang, n_
         assert rel_err(outs[0][i], outs[1][i].astype(np.float64)) < 2e-6
     for k, v in outs[1][2].items():
         np.testing.assert_allclose(outs[0][2][k], v, rtol=1e-5, atol=1e-9, err_msg=k)
+
+
+@pytest.mark.parametrize("n_ang,n_dist,B", [(360, 256, 7), (84, 84, 5)])
+def test_row_product_schedules_are_bit_identical(n_ang, n_dist, B):
+    """The encoder's row products run on single-buffered 64x64 blocks (round 3, eight blocks per CU); the MFMA-paced
+    double-buffered schedule and the 128x96 tile for the N = 96 product stay behind porl_tune_set.  All three walk a
+    tile's reduction in the same order on the same accumulators: features, and the running statistics a train-mode
+    forward leaves behind, are equal bit for bit."""
+    from porl_amd import engine as E
+    from porl_amd.agent.fasternet import FasterNet
+    rng = np.random.default_rng(n_ang + 1)
+    st = np.empty((B, n_ang + 2), dtype=np.float32)
+    st[:, :n_ang] = rng.uniform(0.2, 3.9, size=(B, n_ang))
+    st[:, n_ang:] = rng.uniform(-3, 3, size=(B, 2))
+    outs = []
+    for sb, n96 in ((1, 0), (0, 0), (0, 1), (1, 1)):
+        try:
+            E.tune_set("enc_gemm_sb", sb)
+            E.tune_set("enc_tile_n96", n96)
+            torch.manual_seed(9)
+            m = FasterNet(3, 256, max_batch=8, angle_bins=n_ang, dist_bins=n_dist).to(DEV)
+            m.train()
+            scale = torch.ones(3, B)
+            scale[0, 1] = 0.0
+            a = m(torch.from_numpy(st.copy()).to(DEV), drop_scale=scale).cpu()
+            m.eval()
+            b = m(torch.from_numpy(st.copy()).to(DEV)).cpu()
+            outs.append((a, b, {k: v.cpu() for k, v in m.state_dict().items() if "running" in k}))
+        finally:
+            E.tune_set("enc_gemm_sb", 1)
+            E.tune_set("enc_tile_n96", 0)
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+        for k, v in outs[0][2].items():
+            assert torch.equal(o[2][k], v), k
