@@ -512,6 +512,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
     };
 
     if constexpr (ONEBUF) {
+      // a wave whose whole sub-tile lies outside the problem (N = 96 on 64-wide tiles: the upper half of every second
+      // block) stages operands and meets the barriers but issues no matrix work
+      const bool wave_idle = (n0 + wn * (BN / WN) >= N) || (m0 + wm * (BM / WM) >= M);
       if (nkt > 0) load_tile(ktile(0));
       if constexpr (APRO) __syncthreads();       // the scale / shift table in LDS is complete
       for (int it = 0; it < nkt; ++it) {
@@ -519,6 +522,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const GemmGroup 
         store_tile(ktile(it), 0);                // (waits for the tile's loads)
         if (it + 1 < nkt) load_tile(ktile(it + 1));
         __syncthreads();
+        if (wave_idle) continue;                 // (still takes part in both barriers above)
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
 #pragma unroll
