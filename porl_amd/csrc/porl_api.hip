@@ -304,7 +304,7 @@ int launch_group(GemmGroup& g, int tile, hipStream_t s) {
     const TileCfg tc = tile_cfg(tile);
     label = "gemm_f32_kernel<" + std::to_string(bm) + "," + std::to_string(bn) + "," + std::to_string(GEMM_BK) + "," +
             std::to_string(tc.wm) + "," + std::to_string(tc.wn) + "," + (vec ? "true" : "false") + "," +
-            (apro ? "true" : "false") + ">";
+            (apro ? "true" : "false") + (g.single_buffer && vec && tile == TILE_64x64 ? ",true>" : ">");   // ONEBUF
   }
   ProfScope ps(label, s, flops, bytes);
   hipError_t e = launch_gemm_group(tile, g, s);
