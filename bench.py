@@ -606,16 +606,22 @@ def por_rank(a, force_dp):
         # ~0.1 s, long enough for it to fall back to its idle clocks): same-box comparison with scripts/bench_ramp.py,
         # which spins right before its warm-up updates — 2 965-3 079 updates/s for K = 20 against 2 777-2 852 with the
         # spin-up in front of the agent's construction (gpurun_out/r03/ramp)
-        spinup()
-        for i in range(warmup):
-            one_step(i)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            one_step(warmup + i)
-        agent.flush()                                              # a deferred policy step belongs to the timed work
-        barrier()
-        elapsed = time.perf_counter() - t0
+        import gc
+        gc.collect()                                               # (before the spin-up: a collection between warm-up and the
+        gc.disable()                                               #  timed loop is 20 ms of idle card — 2 690 instead of 2 990)
+        try:                                                       # no collector pause inside a 7 ms timed window
+            spinup()
+            for i in range(warmup):
+                one_step(i)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                one_step(warmup + i)
+            agent.flush()                                          # a deferred policy step belongs to the timed work
+            barrier()
+            elapsed = time.perf_counter() - t0
+        finally:
+            gc.enable()
         if dp:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
