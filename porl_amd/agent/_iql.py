@@ -16,7 +16,7 @@ from ..parallel import GradExchange
 
 # cross-stream ordering of the pipelined update: "signal" = counters in signal memory (engine.py: 3 380 vs 3 300 updates/s),
 # "event" = event record / stream-wait-event pairs (A/B, and the fallback where wait-value operations are missing)
-_PIPE_SYNC = __import__("os").environ.get("PORL_PIPE_SYNC", "signal")
+_PIPE_SYNC = __import__("os").environ.get("PORL_PIPE_SYNC", "signal2")
 # The whole pipelined update from one native call (porl_iql_update_pipelined): "1" always, "0" never, default "auto" =
 # only for small networks, where the host's issue rate is the bound (measured, updates/s, phase calls -> one call:
 # H=256 B=256 9 470 -> 10 990; H=256 B=1024 8 160 -> 8 060; H=1024 B=1024 3 365 -> 3 315 — at GPU-bound sizes the
@@ -267,11 +267,13 @@ class IqlAgentBase(nn.Module):
             main = torch.cuda.current_stream(eng.device)
             eng._seq += 1
             seq = eng._seq
-            # The staging slot loaded next was last read by the policy phase SLOTS = 3 updates ago.  Strictly no wait is
-            # needed for it: this stream has already waited (before its previous value Adam) for the forward half of policy
-            # phase seq - 2, which the in-order side stream only starts after policy phase seq - 3 has finished.  The wait
-            # (and the counter write it pairs with) is kept because it measures FASTER than leaving it out — 3 372 vs
-            # 3 348 updates/s, three runs each on one device (PORL_PIPE_SYNC=signal2 is the variant without).
+            # The staging slot loaded next was last read by the policy phase SLOTS = 3 updates ago.  No wait is needed for
+            # it: this stream has already waited (before its previous value Adam) for the forward half of policy phase
+            # seq - 2, which the in-order side stream only starts after policy phase seq - 3 has finished.  PORL_PIPE_SYNC=
+            # signal adds the explicit wait and the counter write it pairs with: a stream operation holds its queue for
+            # ~5 us plus a gap, and with round 3's kernels the two extra ones cost 2.5-3 % (sustained 3 256-3 291 against
+            # 3 342-3 386 updates/s, two boxes, two runs each, gpurun_out/r03/sig2*; round 2 had measured +0.7 % FOR them,
+            # which is why they were there).
             if _PIPE_SYNC == "signal":
                 eng.wait_signal(eng.SIG_POLICY, seq - eng.SLOTS, main)
         elif pipelined:
