@@ -265,15 +265,21 @@ def measure_sorl_enc(steps, warmup, batch=512, angle_bins=360, dist_bins=256, en
         k = i % nb
         agent.update(st[k, 0], act[k], rew[k], st[k, 1], done[k])
 
-    for i in range(warmup):
-        one_step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        one_step(i)
-    agent.flush()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    import gc
+    gc.collect()
+    gc.disable()                                   # (a collector pause inside a 50 ms window showed up as 614 instead of 930 updates/s)
+    try:
+        for i in range(warmup):
+            one_step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one_step(i)
+        agent.flush()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    finally:
+        gc.enable()
     losses = agent._engine.stats[:2].cpu().numpy()
     if not np.isfinite(losses).all():
         raise RuntimeError("non-finite loss in the SORL + encoder run")
