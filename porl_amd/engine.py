@@ -64,8 +64,9 @@ class IqlEngine:
         return self._events[i]
 
     # Cross-stream ordering of the pipelined update by counters in signal memory (csrc: porl_signal_*).  Three counters:
-    # 0 = value Adam done (update number), 1 = policy forward half done, 2 = policy phase done.  PORL_PIPE_SYNC=event
-    # keeps the event record / stream-wait-event pairs (A/B).
+    # 0 = value Adam done (update number), 1 = policy forward half done, 2 = policy phase done (written and waited for
+    # only under PORL_PIPE_SYNC=signal; the default, signal2, relies on the in-order side stream for slot reuse).
+    # PORL_PIPE_SYNC=event keeps the event record / stream-wait-event pairs (A/B).
     SIG_VALUE, SIG_FWD, SIG_POLICY = 0, 1, 2
 
     def signals(self):
