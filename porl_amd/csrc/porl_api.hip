@@ -142,7 +142,10 @@ int g_enc_pconv_mfma = 0;    // porl_tune_set("enc_pconv_mfma", 1): the fp32 par
 int g_enc_bn_sweep = 0;      // porl_tune_set("enc_bn_sweep", 1): BatchNorm + ReLU of the MLP blocks as a separate sweep (cross-check)
 int g_enc_dense_patch = 0;   // porl_tune_set("enc_dense_patch", 1): rasterise + dense patch embedding (cross-check)
 int g_qnet_fused = 1;     // porl_tune_set("qnet_fused", 0) forces the multi-launch CQL path (A/B measurements)
-int g_qnet_rows16 = 0;      // porl_tune_set("qnet_rows16", 1): 16 rows per block (16x16x4 MFMA tiles) while 32-row blocks leave CUs idle: measured no faster
+// 16 rows per block (v_mfma_f32_16x16x4_f32 tiles) while 32-row blocks would leave CUs idle (config 3 at B = 4096: 128 blocks
+// on 256 CUs).  No faster in round 2; with round 3's loss stage on eight lanes per row it is: 22 800 -> 25 300 updates/s,
+// step kernel 41.4 -> 34.6 us event-timed (gpurun_out/r03: same box, two runs each).  porl_tune_set("qnet_rows16", 0) = A/B.
+int g_qnet_rows16 = 1;
 int g_qnet_two_groups = 1;  // porl_tune_set("qnet_two_groups", 0): the one-group (256-thread) step kernel (A/B, bit-identical)
 
 constexpr int NUM_CU = 256;

@@ -219,7 +219,7 @@ def test_two_group_step_kernel_is_bit_identical_to_the_one_group_kernel(S, A, B,
             out.append([x.clone() for x in (eng.params, eng.adam_m, eng.adam_v, eng.grads, eng.stats[:3], td_abs)])
         finally:
             E.tune_set("qnet_two_groups", 1)
-            E.tune_set("qnet_rows16", 0)
+            E.tune_set("qnet_rows16", 1)                       # the default since round 3
     names = ("params", "adam_m", "adam_v", "grads", "stats", "td_abs")
     for a, b, what in zip(out[0], out[1], names):
         assert torch.equal(a, b), what
