@@ -146,6 +146,7 @@ int g_qnet_fused = 1;     // porl_tune_set("qnet_fused", 0) forces the multi-lau
 // on 256 CUs).  No faster in round 2; with round 3's loss stage on eight lanes per row it is: 22 800 -> 25 300 updates/s,
 // step kernel 41.4 -> 34.6 us event-timed (gpurun_out/r03: same box, two runs each).  porl_tune_set("qnet_rows16", 0) = A/B.
 int g_qnet_rows16 = 1;
+int g_qnet_wgrad_share = 11;   // porl_tune_set("qnet_wgrad_share", s): sixteenths of a 32-tile layer's dW tiles the dW group keeps (16 = all: round 2's split)
 int g_qnet_two_groups = 1;  // porl_tune_set("qnet_two_groups", 0): the one-group (256-thread) step kernel (A/B, bit-identical)
 
 constexpr int NUM_CU = 256;
@@ -1488,6 +1489,7 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "iql_pad_min_k")) { g_iql_pad_min_k = std::max(0, value); return PORL_OK; }
   if (!strcmp(key, "qnet_fused")) { g_qnet_fused = value != 0; return PORL_OK; }
   if (!strcmp(key, "qnet_two_groups")) { g_qnet_two_groups = value != 0; return PORL_OK; }
+  if (!strcmp(key, "qnet_wgrad_share")) { g_qnet_wgrad_share = std::max(1, std::min(value, 16)); return PORL_OK; }
   if (!strcmp(key, "qnet_rows16")) { g_qnet_rows16 = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_dense_patch")) { g_enc_dense_patch = value != 0; return PORL_OK; }
   if (!strcmp(key, "enc_s2d")) { g_enc_s2d = value != 0; return PORL_OK; }
@@ -1905,6 +1907,7 @@ static int qnet_fused_backward(porl_qnet* h, const porl_qnet_hyper* hp, int B, c
     a.idx = nullptr;
   }
   const bool rows16 = two && g_qnet_rows16 && h->fused16_lds_w2 > 0 && cdiv(B, QF_ROWS) < NUM_CU;
+  a.wgrad_share = g_qnet_wgrad_share;
   const int nblk = cdiv(B, rows16 ? 16 : QF_ROWS);
   if (rows16) {
     const QnetFusedArgs& f16 = h->fargs16;

@@ -55,6 +55,7 @@ struct QnetFusedArgs {
   // [0, samp_n) — the keyed Feistel permutation of porl_sample_indices (kernels.hpp: feistel_index) — computed by the
   // block's first lanes instead of being read from `idx`: no sampler launch, no index round trip at kernel entry.
   long samp_n; unsigned long long samp_seed, samp_step; int samp_hb;
+  int wgrad_share;                   // 16-row kernel: sixteenths of a big layer's dW tiles left to the dW group (0 or 16: all)
 };
 
 typedef float qf_f32x16 __attribute__((ext_vector_type(16)));
@@ -825,15 +826,18 @@ __device__ __forceinline__ void qf16_dgrad(const float* dz, int lddz, const floa
 
 // dW_l = dZ^T . in over the block's 16 rows: 16 x 16 tiles of (n, k), four MFMAs each, dealt over `nw` waves; db_l = column
 // sums of dZ over `nt` threads.  Tiles that lie entirely in the padding are skipped.
+// (tile_lo, tile_hi): the share of the layer's tiles this call covers, as sixteenths of the tile count — the dZ-chain
+// group takes the upper share of the 32-tile layers after its own product (qnet_fused2_kernel), nt = 0 skips db
 __device__ __forceinline__ void qf16_wgrad(const QnetFusedArgs& a, int l, const float* dz, const float* in, float* slab, int w,
-                                           int nw, int l16, int kq, int t, int nt) {
+                                           int nw, int l16, int kq, int t, int nt, int share_lo = 0, int share_hi = 16) {
   const int N = a.dims[l + 1], K = a.dims[l];
   const int lddz = qf_r32(N) + 4, ldin = qf_r32(K) + 4;
   const int tiles_n = (N + 15) / 16, tiles_k = (K + 15) / 16;
   float* const wslab = slab + a.w_off[l];
   float* const bslab = slab + a.b_off[l];
   const int ldp = qf_rk(K) + 4;
-  for (int tile = w; tile < tiles_n * tiles_k; tile += nw) {
+  const int T = tiles_n * tiles_k;
+  for (int tile = T * share_lo / 16 + w; tile < T * share_hi / 16; tile += nw) {
     const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
     float av[4], bv[4];
 #pragma unroll
@@ -852,6 +856,7 @@ __device__ __forceinline__ void qf16_wgrad(const QnetFusedArgs& a, int l, const 
     for (int i = 0; i < 4; ++i)
       if (tn * 16 + 4 * kq + i < N && k < K) wp[i * ldp] = acc[i] + acc1[i];
   }
+  if (nt > 0)
   for (int n = t; n < N; n += nt) {
     float v[16];
 #pragma unroll
@@ -901,10 +906,12 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
   //   group 0: target layers 0..L, then the online layers L..1 (dgrad)
   //   group 1: [Double DQN: online layers 0..L for the pass over s',] online layers 0..L
   const int n_lead = dd ? L + 1 : 0;
-  auto dma = [&](int j, float* dst) __attribute__((always_inline)) {
+  // (as_grp: whose stage list j refers to — the loss stage has the idle group issue the other group's next image)
+  auto dma = [&](int j, float* dst, int as_grp = -1) __attribute__((always_inline)) {
     int l;
     const float* P = a.params;
-    if (grp) l = j < n_lead ? j : j - n_lead;
+    const int g_ = as_grp < 0 ? grp : as_grp;
+    if (g_) l = j < n_lead ? j : j - n_lead;
     else if (j <= L) { l = j; P = a.params_tgt; }
     else l = 2 * L + 1 - j;
     const float* img = P + a.w_off[l];
@@ -994,13 +1001,15 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
   // the two buffers alternate from there (bsel), and W_{L-1} is requested into wbuf0 now — every wave is past the last
   // forward barrier, so group 0's forward buffer is dead — and lands while the loss is computed.
   auto bsel = [&](int l) __attribute__((always_inline)) { return ((L - l) & 1) ? wbuf0 : wbuf1; };
-  if (grp == 0 && L > 1) dma(L + 2, bsel(L - 1));
+  // (issued by group 1, which has nothing else to do during the loss: a group's four waves need ~2 k cycles to issue an
+  //  image, and group 0 used to spend them in front of the loss arithmetic)
+  if (grp == 1 && L > 1) dma(L + 2, bsel(L - 1), 0);
   const bool wide = qf_loss_wide_ok(a);
   if (grp == 0) {
     if (wide) qf_loss_rows8(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, act8, rew8, done8, row0, tg, red, ROWS);
     else qf_loss_rows(a, qf_lds + a.lds_act[L + 1], Qn, dz, amax, row_act, row_rew, row_done, row0, lane, wave, red, ROWS);
   }
-  if (grp == 0) barrier_vm(); else qf_barrier();
+  barrier_vm();                                    // group 1's image has landed, group 0's loss rows are written
   if (t == 0) {
     a.part_td[blockIdx.x] = wide ? ((red[0] + red[2]) + red[4]) + red[6] : red[0];
     a.part_pen[blockIdx.x] = wide ? ((red[1] + red[3]) + red[5]) + red[7] : red[1];
@@ -1018,16 +1027,22 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
     const int lddz = qf_r32(N) + 4, ldin = qf_r32(K) + 4;
     const float* in = qf_lds + a.lds_act[l];
     float* dzp = qf_lds + a.lds_tmp[l & 1];                           // dZ_l lives in tmp[(l + 1) & 1]
+    const int wshare = (ROWS == 16 && a.wgrad_share > 0 && ((N + 15) / 16) * ((K + 15) / 16) >= 16) ? a.wgrad_share : 16;
     if (grp == 0) {
       if (l < L && l > 1) dma(2 * L + 2 - l, bsel(l - 1));            // W_{l-1} into the buffer dgrad(l + 1) is done with
       stamp();
       if constexpr (ROWS == 16) qf16_dgrad(dz, lddz, bsel(l), N, K, in, ldin, dzp, wave, l16, kq);
       else qf_dgrad(dz, lddz, bsel(l), N, K, in, ldin, dzp, wave, li, kh);
+      // 16-row blocks: the dW tiles of a 128-wide layer keep group 1 busy for ~8.7 k cycles while this group's product
+      // takes ~3 k (stamps: scripts/bench_cql_prof.py) — it takes the upper 5/16 of the tiles behind its product
+      if constexpr (ROWS == 16) {
+        if (wshare < 16) qf16_wgrad(a, l, dz, in, slab, wave, 4, l16, kq, 0, 0, wshare, 16);
+      }
       stamp();
       barrier_vm();
     } else {
       stamp2();
-      if constexpr (ROWS == 16) qf16_wgrad(a, l, dz, in, slab, wave, 4, l16, kq, tg, 256);
+      if constexpr (ROWS == 16) qf16_wgrad(a, l, dz, in, slab, wave, 4, l16, kq, tg, 256, 0, wshare);
       else qf_wgrad_n(a, l, dz, in, slab, wave, 4, li, kh, tg, 256);
       stamp2();
       qf_barrier();
