@@ -722,14 +722,17 @@ __device__ __forceinline__ void qf_input_store(const QfInput& in, float* dst, in
   }
 }
 
-// ---- 16 minibatch rows per block on v_mfma_f32_16x16x4_f32 (opt-in: porl_tune_set("qnet_rows16", 1)) ---------------
+// ---- 16 minibatch rows per block on v_mfma_f32_16x16x4_f32 (the default since round 3 while 32-row blocks would leave
+// ---- CUs idle; porl_tune_set("qnet_rows16", 0) = the 32-row kernel) -----------------------------------------------------
 // Config 3 at B = 4096 is 128 blocks of 32 rows: half of the chip idles, and inside a block the stage time is the
 // dependent chain of 64-cycle 32x32x2 MFMAs of one or two column slabs.  With 16 rows per block the same batch is 256
 // blocks, and a layer is 16 x 16 tiles (32-cycle MFMAs over 4 reduction indices): a 64-wide layer is four tiles = one
 // per wave, its chain K/4 x 32 cycles — a quarter of the 32-row kernel's.  MEASURED: no faster (43.2 vs 42.4 us; the
 // dZ chain 9.6 k -> 3.9 k cycles per layer, but a forward tile of 16 MFMAs takes 2.3-3.7 k cycles where the bare
 // instruction stream (scripts/mfma_rate.hip: 32.2 cycles per MFMA, 86 with LDS operands at two waves per SIMD) needs
-// 1.4 k, and the 256 partial-gradient slabs cost the reduce launch +1.8 us) — so 32 rows stay the default.  The stage
+// 1.4 k, and the 256 partial-gradient slabs cost the reduce launch +1.8 us) — in ROUND 2.  Round 3: with the loss
+// stage on eight lanes per row, the dW tiles shared between the wave groups and the loss-stage weight request moved to
+// the idle group, this form runs 26 400 updates/s against 22 800 (step kernel ~31 against 38.8 us by rocprofv3).  The stage
 // time of these kernels is not the matrix pipe's.  Lane l = (l16 = l & 15, kq = l >> 4) supplies
 // A[row l16][k] and B[k][col l16] for k = 4 kq + j in MFMA j of a batch of 16 reduction indices (any k order is legal as
 // long as A and B agree), so each operand is ONE 16-byte read per batch; D register i is row 4 kq + i, column l16.
