@@ -675,37 +675,41 @@ __global__ __launch_bounds__(256) void qnet_fused_kernel(const QnetFusedArgs a) 
 // branch per slot — `if (u * 256 < total)`, `idx ? idx[b] : b` — the compiler closed every slot with s_waitcnt
 // vmcnt(0): nine dependent round trips to HBM at kernel entry instead of two, ~12 k cycles.)
 struct QfInput { long row[QF_XREGS]; float v[QF_XREGS]; };
+// NU: staging slots per thread that can be live for the block's row count (ceil(rows * (QF_MAX_W + 4) / 256): 17 for 32
+// rows, 9 for 16 — the 16-row kernel spent 2.9 k cycles of its entry on the 17-slot form's row-number look-ups)
+template <int NU = QF_XREGS>
 __device__ __forceinline__ void qf_input_rows(QfInput& in, int ld, const int64_t* idx, int row0, int B, int t, int rows = QF_ROWS,
                                               const long* lds_rows = nullptr) {
   const int total = rows * ld;
   const float inv_ld = 1.0f / (float)ld;
   if (lds_rows) {                                     // sampled in the kernel: the block's row numbers sit in LDS
 #pragma unroll
-    for (int u = 0; u < QF_XREGS; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int i = u * 256 + t;
       in.row[u] = lds_rows[qf_div(i < total ? i : 0, inv_ld)];
     }
   } else if (idx) {
 #pragma unroll
-    for (int u = 0; u < QF_XREGS; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int i = u * 256 + t;
       const int b = row0 + qf_div(i < total ? i : 0, inv_ld);
       in.row[u] = idx[b < B ? b : 0];
     }
   } else {
 #pragma unroll
-    for (int u = 0; u < QF_XREGS; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int i = u * 256 + t;
       in.row[u] = row0 + qf_div(i < total ? i : 0, inv_ld);
     }
   }
 }
+template <int NU = QF_XREGS>
 __device__ __forceinline__ void qf_input_load(QfInput& in, int ld, const float* src, long rs, int row0, int B, int cols, int t,
                                               int rows = QF_ROWS) {
   const int total = rows * ld;
   const float inv_ld = 1.0f / (float)ld;
 #pragma unroll
-  for (int u = 0; u < QF_XREGS; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int i = u * 256 + t;
     const int r = qf_div(i < total ? i : 0, inv_ld), c = i - r * ld;
     const bool ok = i < total && row0 + r < B && c < cols;
@@ -713,10 +717,11 @@ __device__ __forceinline__ void qf_input_load(QfInput& in, int ld, const float* 
     in.v[u] = ok ? x : 0.f;
   }
 }
+template <int NU = QF_XREGS>
 __device__ __forceinline__ void qf_input_store(const QfInput& in, float* dst, int ld, int t, int rows = QF_ROWS) {
   const int total = rows * ld;
 #pragma unroll
-  for (int u = 0; u < QF_XREGS; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int i = u * 256 + t;
     if (i < total) dst[i] = in.v[u];
   }
@@ -950,11 +955,12 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
     dma(0, wl);                                      // (in flight across the barrier: it is an asm statement)
     qf_barrier();
   }
-  qf_input_rows(xin, ldx, a.idx, row0, a.B, tg, ROWS, sampled ? srow : nullptr);
+  constexpr int NU = (ROWS * (QF_MAX_W + 4) + 255) / 256;
+  qf_input_rows<NU>(xin, ldx, a.idx, row0, a.B, tg, ROWS, sampled ? srow : nullptr);
   const int my_row = row0 + (t < ROWS ? t : 0);
   const long my_src = sampled ? srow[t < ROWS ? t : 0] : (my_row < a.B ? (a.idx ? a.idx[my_row] : (long)my_row) : 0L);
   if (!sampled) dma(0, wl);
-  qf_input_load(xin, ldx, grp ? a.states : a.next_states, grp ? a.s_rs : a.n_rs, row0, a.B, a.dims[0], tg, ROWS);
+  qf_input_load<NU>(xin, ldx, grp ? a.states : a.next_states, grp ? a.s_rs : a.n_rs, row0, a.B, a.dims[0], tg, ROWS);
   const int row_act = (int)a.actions[my_src];
   const float row_rew = a.rew[my_src], row_done = a.done[my_src];
   // the same in the 8-lanes-per-row mapping of qf_loss_rows8 (thread tg of group 0 -> row tg / 8)
@@ -962,7 +968,7 @@ __global__ __launch_bounds__(512) void qnet_fused2_kernel(const QnetFusedArgs a,
   const long my_src8 = sampled ? srow[r8] : (row0 + r8 < a.B ? (a.idx ? a.idx[row0 + r8] : (long)(row0 + r8)) : 0L);
   const int act8 = (int)a.actions[my_src8];
   const float rew8 = a.rew[my_src8], done8 = a.done[my_src8];
-  qf_input_store(xin, grp ? X : Xn, ldx, tg, ROWS);
+  qf_input_store<NU>(xin, grp ? X : Xn, ldx, tg, ROWS);
   stamp();
 
   // ---- forward: role 1 = target net on s' (ping-pong in tmp), 2 = online net on s' (Double DQN: argmax kept),
