@@ -133,8 +133,18 @@ int g_skinny = 7;
 // there the policy phase is not the critical stream, and shortening its launches moved the two queues against each other
 // — same-box A/B (gpurun_out/r03/ab3.log, sustained updates/s, two runs each): mask 0: 3 306 / 3 309; 7: 3 206 / 3 204; 4:
 // 3 233 / 3 238; 6: 3 221 / 3 218 — while the one-stream update gains 10-12 us (380 -> 369 us event-timed).
-int g_skinny_pipelined = 0;
-inline int skinny_mask() { return g_short_blocks ? g_skinny_pipelined : g_skinny; }
+// Round 3, later: that holds for H = 1024, where the big products dominate.  At H = 256 (B = 1024) the update is a chain
+// of short launches and the skinny kernels are worth +10 % pipelined as well (8 600 -> 9 530 updates/s), at H = 512
+// +0.5 ... +5 % (6 570-6 860 -> 6 890-6 950), at H = 768 +2 % (4 490 -> 4 570), two runs each: -1 = by width — on up to
+// `g_skinny_pipelined_max_h`, off above.
+int g_skinny_pipelined = -1;
+int g_skinny_pipelined_max_h = 768;
+thread_local int g_cur_hidden = 0;              // hidden width of the engine whose entry point is running (check_ready)
+inline int skinny_mask() {
+  if (!g_short_blocks) return g_skinny;
+  if (g_skinny_pipelined >= 0) return g_skinny_pipelined;
+  return g_cur_hidden <= g_skinny_pipelined_max_h ? g_skinny : 0;
+}
 int g_dw0_slabs = 16;        // porl_tune_set("dw0_slabs", n <= SK_MAX): slabs of the skinny dW0 kernel (A/B: fewer slabs = fewer partial bytes, fewer blocks)
 int g_iql_fold = 1;          // porl_tune_set("iql_fold", 0): porl_iql_step keeps the slab combines as launches of their own (A/B)
 int g_enc_bf16_operands_only = 0;   // porl_tune_set("enc_bf16_operands_only", 1): compute_dtype="bf16" runs round 2's bf16-OPERAND mode (fp32 tensors in memory) instead of encoder_bf16.hpp (A/B)
@@ -367,6 +377,7 @@ int check_ready(const porl_iql* h, bool need_batch) {
   if (!h->bound) PORL_FAIL(PORL_ERR_UNBOUND, "porl_iql_bind() has not been called");
   if (need_batch && h->batch <= 0) PORL_FAIL(PORL_ERR_INVALID, "no minibatch loaded (porl_iql_load_batch)");
   g_short_blocks = (h->mode & PORL_IQL_MODE_SHORT_BLOCKS) != 0;
+  g_cur_hidden = h->cfg.hidden_dim;
   return 0;
 }
 
@@ -1501,7 +1512,8 @@ int porl_tune_set(const char* key, int value) {
   if (!strcmp(key, "enc_bf16_operands_only")) { g_enc_bf16_operands_only = value != 0; return PORL_OK; }
   if (!strcmp(key, "iql_fold")) { g_iql_fold = value != 0; return PORL_OK; }
   if (!strcmp(key, "skinny")) { g_skinny = value == 1 ? 7 : value; return PORL_OK; }
-  if (!strcmp(key, "skinny_pipelined")) { g_skinny_pipelined = value == 1 ? 7 : value; return PORL_OK; }
+  if (!strcmp(key, "skinny_pipelined")) { g_skinny_pipelined = value == 1 ? 7 : value; return PORL_OK; }     // -1: by width
+  if (!strcmp(key, "skinny_pipelined_max_h")) { g_skinny_pipelined_max_h = value; return PORL_OK; }
   if (!strcmp(key, "dw0_slabs")) { g_dw0_slabs = std::max(1, std::min(value, SK_MAX)); return PORL_OK; }
   if (!strcmp(key, "l0_tile")) { g_l0_tile = value; return PORL_OK; }
   if (!strcmp(key, "l0_kernel")) { g_l0_kernel = value != 0; return PORL_OK; }

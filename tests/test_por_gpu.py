@@ -358,7 +358,7 @@ def same_kernels_in_both_modes(request):
     E.tune_set("skinny_pipelined", request.param)
     yield request.param
     E.tune_set("skinny", 7)
-    E.tune_set("skinny_pipelined", 0)
+    E.tune_set("skinny_pipelined", -1)          # the default: by hidden width (on up to 512, off above)
 
 
 def test_pipelined_updates_are_bit_identical_to_back_to_back_updates(same_kernels_in_both_modes):
